@@ -1,0 +1,294 @@
+"""ctypes binding of the device layer's C ABI (include/bxh.h).
+
+Python is plumbing here (tests, bench.py, torch.distributed launch): the
+product is `baryonyx_amd/csrc/libbxh.so`.  There is no fallback: if the shared
+library is missing or HIP cannot run, every call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libbxh.so")
+
+i32p = C.POINTER(C.c_int32)
+f64p = C.POINTER(C.c_double)
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+
+BXH_OK = 0
+BXH_ERR_INVALID = -1
+BXH_ERR_OOM = -2
+BXH_ERR_UNSUPPORTED = -3
+BXH_ERR_DEVICE = -4
+
+# every symbol include/bxh.h declares (tests check the library exports them)
+SYMBOLS = [
+    "bxh_last_error", "bxh_create", "bxh_destroy", "bxh_set_stream", "bxh_batch",
+    "bxh_nwords", "bxh_rmax", "bxh_set_x", "bxh_get_x", "bxh_set_pi", "bxh_get_pi",
+    "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset",
+    "bxh_order_init", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
+    "bxh_status_sync", "bxh_row_bytes",
+]
+
+
+class BxhProblem(C.Structure):
+    _fields_ = [
+        ("m", C.c_int32),
+        ("n", C.c_int32),
+        ("nnz", C.c_int64),
+        ("row_ptr", i32p),
+        ("col", i32p),
+        ("factor", i32p),
+        ("cmin", i32p),
+        ("cmax", i32p),
+        ("cost", f64p),
+        ("n_quad", C.c_int32),
+        ("q_ptr", i32p),
+        ("q_id", i32p),
+        ("q_factor", f64p),
+    ]
+
+
+class BxhSweepArgs(C.Structure):
+    _fields_ = [
+        ("kappa", f64p),
+        ("delta", C.c_double),
+        ("theta", C.c_double),
+        ("obj_amp", C.c_double),
+        ("is_push", C.c_int32),
+        ("order", C.c_int32),
+        ("active", u8p),
+    ]
+
+
+class BxhStatus(C.Structure):
+    _fields_ = [
+        ("remaining", C.c_int32),
+        ("pi_changed", C.c_int32),
+        ("rng", C.c_uint32),
+        ("rows_in_sweep", C.c_uint32),
+        ("row_updates", C.c_uint64),
+    ]
+
+
+STATUS_DTYPE = np.dtype(
+    [
+        ("remaining", np.int32),
+        ("pi_changed", np.int32),
+        ("rng", np.uint32),
+        ("rows_in_sweep", np.uint32),
+        ("row_updates", np.uint64),
+    ]
+)
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/bxh_device.hip for gfx950 into csrc/libbxh.so (in-tree, so
+    it travels with the repository snapshot)."""
+    srcs = [os.path.join(CSRC, f) for f in ("bxh_device.hip", "bxh_kernels.hpp")]
+    srcs.append(os.path.join(_HERE, "..", "include", "bxh.h"))
+    stale = force or not os.path.exists(LIB_PATH)
+    if not stale:
+        t = os.path.getmtime(LIB_PATH)
+        stale = any(os.path.getmtime(s) > t for s in srcs)
+    if stale:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call(
+            [hipcc, *HIPCC_FLAGS, "-o", LIB_PATH, os.path.join(CSRC, "bxh_device.hip")]
+        )
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    """Load libbxh.so; raises if it has not been built (no silent fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+            )
+        L = C.CDLL(LIB_PATH)
+        L.bxh_last_error.restype = C.c_char_p
+        L.bxh_create.argtypes = [
+            C.POINTER(BxhProblem), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+            C.POINTER(C.c_void_p),
+        ]
+        L.bxh_destroy.argtypes = [C.c_void_p]
+        L.bxh_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        for nm in ("bxh_batch", "bxh_nwords", "bxh_rmax"):
+            getattr(L, nm).argtypes = [C.c_void_p]
+        L.bxh_set_x.argtypes = [C.c_void_p, C.c_int, u64p]
+        L.bxh_get_x.argtypes = [C.c_void_p, C.c_int, u64p]
+        for nm in ("bxh_set_pi", "bxh_get_pi", "bxh_set_P", "bxh_get_P"):
+            getattr(L, nm).argtypes = [C.c_void_p, C.c_int, f64p]
+        L.bxh_set_rng.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        L.bxh_get_rng.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
+        L.bxh_reset.argtypes = [C.c_void_p, C.c_int]
+        L.bxh_order_init.argtypes = [C.c_void_p, C.c_int, i32p]
+        L.bxh_get_violated.argtypes = [C.c_void_p, C.c_int, i32p, i32p]
+        L.bxh_sweep.argtypes = [C.c_void_p, C.POINTER(BxhSweepArgs), C.c_void_p]
+        L.bxh_sweep_async.argtypes = [C.c_void_p, C.POINTER(BxhSweepArgs)]
+        L.bxh_status_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.bxh_row_bytes.argtypes = [C.c_void_p, f64p]
+        _LIB = L
+    return _LIB
+
+
+class BxhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"bxh error {code}: {msg}")
+        self.code = code
+
+
+def _check(rc):
+    if rc != 0:
+        raise BxhError(rc, lib().bxh_last_error().decode())
+
+
+def _p(a, typ):
+    return a.ctypes.data_as(typ)
+
+
+class DeviceBatch:
+    """`batch` Solver instances of one constraint matrix on one MI355X.
+
+    Mirrors the reference's Solver concept: `x`, `pi`, `P`,
+    `rng` per instance, `order_init` == compute_order::init, `sweep` ==
+    compute_order::run / push_and_run for every instance at once.
+    """
+
+    def __init__(self, inst, cost, batch, kind=None, float_type=1, maximize=None, device=0):
+        self.L = lib()
+        self.inst = inst
+        self.batch = int(batch)
+        self.kind = inst.kind if kind is None else kind
+        self.maximize = inst.maximize if maximize is None else maximize
+        self._keep = dict(
+            row_ptr=np.ascontiguousarray(inst.row_ptr, np.int32),
+            col=np.ascontiguousarray(inst.col, np.int32),
+            factor=np.ascontiguousarray(inst.factor, np.int32),
+            cmin=np.ascontiguousarray(inst.cmin, np.int32),
+            cmax=np.ascontiguousarray(inst.cmax, np.int32),
+            cost=np.ascontiguousarray(cost, np.float64),
+        )
+        k = self._keep
+        assert k["cost"].shape[0] == inst.n
+        pb = BxhProblem(
+            inst.m, inst.n, inst.nnz,
+            _p(k["row_ptr"], i32p), _p(k["col"], i32p), _p(k["factor"], i32p),
+            _p(k["cmin"], i32p), _p(k["cmax"], i32p), _p(k["cost"], f64p),
+            0, None, None, None,
+        )
+        h = C.c_void_p()
+        _check(self.L.bxh_create(C.byref(pb), self.kind, float_type, int(self.maximize),
+                                 self.batch, device, C.byref(h)))
+        self.h = h
+        self.nwords = self.L.bxh_nwords(self.h)
+        self.rmax = self.L.bxh_rmax(self.h)
+        self._status = np.zeros(self.batch, STATUS_DTYPE)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bxh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(self.L.bxh_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_x(self, i, words):
+        w = np.ascontiguousarray(words, np.uint64)
+        assert w.shape[0] == self.nwords
+        _check(self.L.bxh_set_x(self.h, i, _p(w, u64p)))
+
+    def get_x(self, i):
+        w = np.zeros(self.nwords, np.uint64)
+        _check(self.L.bxh_get_x(self.h, i, _p(w, u64p)))
+        return w
+
+    def set_pi(self, i, v):
+        v = np.ascontiguousarray(v, np.float64)
+        assert v.shape[0] == self.inst.m
+        _check(self.L.bxh_set_pi(self.h, i, _p(v, f64p)))
+
+    def get_pi(self, i):
+        v = np.zeros(self.inst.m, np.float64)
+        _check(self.L.bxh_get_pi(self.h, i, _p(v, f64p)))
+        return v
+
+    def set_P(self, i, v):
+        v = np.ascontiguousarray(v, np.float64)
+        assert v.shape[0] == self.inst.nnz
+        _check(self.L.bxh_set_P(self.h, i, _p(v, f64p)))
+
+    def get_P(self, i):
+        v = np.zeros(self.inst.nnz, np.float64)
+        _check(self.L.bxh_get_P(self.h, i, _p(v, f64p)))
+        return v
+
+    def set_rng(self, i, s):
+        _check(self.L.bxh_set_rng(self.h, i, int(s)))
+
+    def get_rng(self, i):
+        s = C.c_uint32()
+        _check(self.L.bxh_get_rng(self.h, i, C.byref(s)))
+        return s.value
+
+    def reset(self, i):
+        _check(self.L.bxh_reset(self.h, i))
+
+    def order_init(self, order=0):
+        rem = np.zeros(self.batch, np.int32)
+        _check(self.L.bxh_order_init(self.h, order, _p(rem, i32p)))
+        return rem
+
+    def violated(self, i):
+        rows = np.zeros(self.inst.m, np.int32)
+        cnt = C.c_int32()
+        _check(self.L.bxh_get_violated(self.h, i, _p(rows, i32p), C.byref(cnt)))
+        return rows[: cnt.value].copy()
+
+    def _args(self, kappa, delta, theta, is_push, obj_amp, order, active):
+        kap = np.ascontiguousarray(np.broadcast_to(np.asarray(kappa, np.float64), (self.batch,)))
+        act = None
+        if active is not None:
+            act = np.ascontiguousarray(active, np.uint8)
+        a = BxhSweepArgs(_p(kap, f64p), delta, theta, obj_amp, int(is_push), order,
+                         _p(act, u8p) if act is not None else None)
+        return a, (kap, act)
+
+    def sweep(self, kappa, delta, theta, is_push=False, obj_amp=0.0, order=0, active=None):
+        a, keep = self._args(kappa, delta, theta, is_push, obj_amp, order, active)
+        _check(self.L.bxh_sweep(self.h, C.byref(a), self._status.ctypes.data_as(C.c_void_p)))
+        return self._status.copy()
+
+    def sweep_async(self, kappa, delta, theta, is_push=False, obj_amp=0.0, order=0, active=None):
+        a, keep = self._args(kappa, delta, theta, is_push, obj_amp, order, active)
+        _check(self.L.bxh_sweep_async(self.h, C.byref(a)))
+
+    def status(self):
+        _check(self.L.bxh_status_sync(self.h, self._status.ctypes.data_as(C.c_void_p)))
+        return self._status.copy()
+
+    def row_bytes(self):
+        b = np.zeros(self.inst.m, np.float64)
+        _check(self.L.bxh_row_bytes(self.h, _p(b, f64p)))
+        return b

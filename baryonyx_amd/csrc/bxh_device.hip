@@ -1,0 +1,773 @@
+// baryonyx_amd/csrc/bxh_device.hip -- host half of the C ABI in include/bxh.h:
+// builds the device-resident constraint matrix, owns the per-instance solver
+// state, launches the gfx950 kernels of bxh_kernels.hpp.
+//
+// There is deliberately NO CPU implementation behind these entry points: if
+// HIP cannot run them they return BXH_ERR_DEVICE.
+#include "../../include/bxh.h"
+#include "bxh_kernels.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_error;
+
+int
+fail(int code, const std::string& msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess)                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? BXH_ERR_OOM                \
+                                                  : BXH_ERR_DEVICE,            \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+template<typename T>
+struct DevBuf
+{
+    T* p = nullptr;
+    size_t count = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    hipError_t alloc(size_t n)
+    {
+        release();
+        count = n;
+        return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& v)
+    {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty())
+            return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+} // namespace
+
+struct bxh_handle_s
+{
+    int device = 0;
+    int kind = 0, float_type = 1, maximize = 0, batch = 0;
+    int m = 0, n = 0, nnz = 0, rmax = 0, nwords = 0;
+    size_t fsize = 8;
+    int threads = 256;
+    size_t lds_bytes = 0;
+
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // problem
+    DevBuf<int> row_ptr, row_col, row_pos, col_ptr, col_row, bmin, bmax, bneg;
+    DevBuf<signed char> fac_csr, fac_csc;
+    DevBuf<unsigned char> cost; // Float[n]
+    // host copies needed for state import/export and accounting
+    std::vector<int> h_row_pos, h_row_ptr, h_col_ptr, h_row_col;
+
+    // state
+    DevBuf<unsigned char> P, pi, rstale;
+    DevBuf<unsigned> x;
+    DevBuf<int> vlist, vcount;
+    DevBuf<signed char> vflag;
+    DevBuf<bxh::DevStatus> status;
+    DevBuf<double> kappa;
+    DevBuf<unsigned char> active;
+
+    bxh::DevStatus* h_status = nullptr; // pinned
+    double* h_kappa = nullptr;          // pinned
+    unsigned char* h_active = nullptr;  // pinned
+
+    bxh::DevProblem dp{};
+    bxh::DevState ds{};
+
+    ~bxh_handle_s()
+    {
+        if (h_status)
+            (void)hipHostFree(h_status);
+        if (h_kappa)
+            (void)hipHostFree(h_kappa);
+        if (h_active)
+            (void)hipHostFree(h_active);
+        if (own_stream)
+            (void)hipStreamDestroy(own_stream);
+    }
+};
+
+namespace {
+
+int
+check_inst(bxh_handle h, int inst)
+{
+    if (!h)
+        return fail(BXH_ERR_INVALID, "null handle");
+    if (inst < 0 || inst >= h->batch)
+        return fail(BXH_ERR_INVALID, "instance index out of range");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess)
+        return fail(BXH_ERR_DEVICE, hipGetErrorString(e));
+    return BXH_OK;
+}
+
+template<typename Float>
+void
+to_float(const double* in, size_t n, std::vector<unsigned char>& out)
+{
+    out.resize(n * sizeof(Float));
+    Float* o = reinterpret_cast<Float*>(out.data());
+    for (size_t i = 0; i != n; ++i)
+        o[i] = static_cast<Float>(in[i]);
+}
+
+template<typename Float>
+void
+from_float(const std::vector<unsigned char>& in, size_t n, double* out)
+{
+    const Float* p = reinterpret_cast<const Float*>(in.data());
+    for (size_t i = 0; i != n; ++i)
+        out[i] = static_cast<double>(p[i]);
+}
+
+int
+set_vec(bxh_handle h, unsigned char* dst, const double* src, size_t n)
+{
+    std::vector<unsigned char> tmp;
+    if (h->float_type == BXH_FLOAT)
+        to_float<float>(src, n, tmp);
+    else
+        to_float<double>(src, n, tmp);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(dst, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+    return BXH_OK;
+}
+
+int
+get_vec(bxh_handle h, const unsigned char* src, double* dst, size_t n)
+{
+    std::vector<unsigned char> tmp(n * h->fsize);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(tmp.data(), src, tmp.size(), hipMemcpyDeviceToHost));
+    if (h->float_type == BXH_FLOAT)
+        from_float<float>(tmp, n, dst);
+    else
+        from_float<double>(tmp, n, dst);
+    return BXH_OK;
+}
+
+template<typename Float>
+int
+launch_sweep(bxh_handle h, const bxh::DevSweep& a)
+{
+    const bool pm1 = h->kind == BXH_EQ_101 || h->kind == BXH_INEQ_101;
+    if (pm1)
+        hipLaunchKernelGGL((bxh::sweep_kernel<Float, true>),
+                           dim3(h->batch),
+                           dim3(h->threads),
+                           h->lds_bytes,
+                           h->stream,
+                           h->dp,
+                           h->ds,
+                           a);
+    else
+        hipLaunchKernelGGL((bxh::sweep_kernel<Float, false>),
+                           dim3(h->batch),
+                           dim3(h->threads),
+                           h->lds_bytes,
+                           h->stream,
+                           h->dp,
+                           h->ds,
+                           a);
+    HIP_TRY(hipGetLastError());
+    return BXH_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char*
+bxh_last_error(void)
+{
+    return g_error.c_str();
+}
+
+int
+bxh_create(const bxh_problem* pb,
+           int kind,
+           int float_type,
+           int maximize,
+           int batch,
+           int device,
+           bxh_handle* out)
+{
+    if (!pb || !out)
+        return fail(BXH_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (pb->m <= 0 || pb->n <= 0 || pb->nnz <= 0 || batch <= 0)
+        return fail(BXH_ERR_INVALID, "empty problem or batch");
+    if (!pb->row_ptr || !pb->col || !pb->cmin || !pb->cmax || !pb->cost)
+        return fail(BXH_ERR_INVALID, "null problem array");
+    if (kind < BXH_EQ_01 || kind > BXH_INEQ_Z)
+        return fail(BXH_ERR_INVALID, "unknown solver kind");
+    if (kind == BXH_INEQ_Z)
+        return fail(BXH_ERR_UNSUPPORTED,
+                    "inequalities-Z (general integer coefficients) is not on "
+                    "the device yet");
+    if (float_type != BXH_FLOAT && float_type != BXH_DOUBLE)
+        return fail(BXH_ERR_UNSUPPORTED,
+                    "only float and double exist on the device (long double "
+                    "does not)");
+    if (pb->n_quad != 0)
+        return fail(BXH_ERR_UNSUPPORTED,
+                    "quadratic objective terms are not on the device yet");
+    if (pb->nnz > 0x7fffffffLL)
+        return fail(BXH_ERR_UNSUPPORTED, "more than 2^31-1 elements");
+    if (pb->row_ptr[0] != 0 || pb->row_ptr[pb->m] != pb->nnz)
+        return fail(BXH_ERR_INVALID, "row_ptr does not span [0, nnz]");
+
+    hipError_t e0 = hipSetDevice(device);
+    if (e0 != hipSuccess)
+        return fail(BXH_ERR_DEVICE,
+                    std::string("hipSetDevice: ") + hipGetErrorString(e0));
+
+    bxh_handle h = new (std::nothrow) bxh_handle_s;
+    if (!h)
+        return fail(BXH_ERR_OOM, "host allocation failed");
+    std::unique_ptr<bxh_handle_s> guard(h);
+
+    h->device = device;
+    h->kind = kind;
+    h->float_type = float_type;
+    h->maximize = maximize ? 1 : 0;
+    h->batch = batch;
+    h->m = pb->m;
+    h->n = pb->n;
+    h->nnz = static_cast<int>(pb->nnz);
+    h->nwords = pb->n / 64 + 1;
+    h->fsize = float_type == BXH_FLOAT ? 4 : 8;
+
+    const int m = h->m, n = h->n, nnz = h->nnz;
+    const bool pm1 = kind == BXH_EQ_101 || kind == BXH_INEQ_101;
+
+    // ---- validate + CSC (stable by column == counting sort,
+    //      sparse-matrix.hpp:155-174) ---------------------------------------
+    std::vector<int> col_ptr(static_cast<size_t>(n) + 1, 0);
+    int rmax = 0;
+    for (int k = 0; k != m; ++k) {
+        const int len = pb->row_ptr[k + 1] - pb->row_ptr[k];
+        if (len <= 0)
+            return fail(BXH_ERR_INVALID, "empty or negative-length row");
+        rmax = std::max(rmax, len);
+    }
+    for (int e = 0; e != nnz; ++e) {
+        if (pb->col[e] < 0 || pb->col[e] >= n)
+            return fail(BXH_ERR_INVALID, "column index out of range");
+        const int f = pb->factor ? pb->factor[e] : 1;
+        if (pm1 ? (f != 1 && f != -1) : (f != 1))
+            return fail(BXH_ERR_INVALID,
+                        "coefficient not allowed by this solver kind");
+        ++col_ptr[pb->col[e] + 1];
+    }
+    for (int j = 0; j != n; ++j)
+        col_ptr[j + 1] += col_ptr[j];
+    h->rmax = rmax;
+
+    std::vector<int> col_row(static_cast<size_t>(nnz)), row_pos(static_cast<size_t>(nnz));
+    std::vector<signed char> fac_csr(pm1 ? nnz : 0), fac_csc(pm1 ? nnz : 0);
+    {
+        std::vector<int> fill(col_ptr.begin(), col_ptr.end() - 1);
+        for (int k = 0; k != m; ++k)
+            for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e) {
+                const int q = fill[pb->col[e]]++;
+                col_row[q] = k;
+                row_pos[e] = q;
+                if (pm1) {
+                    fac_csr[e] = static_cast<signed char>(pb->factor[e]);
+                    fac_csc[q] = static_cast<signed char>(pb->factor[e]);
+                }
+            }
+    }
+
+    // ---- bounds as each Solver constructor clamps them --------------------
+    std::vector<int> bmin(m), bmax(m), bneg(m, 0);
+    for (int k = 0; k != m; ++k) {
+        const int rs = pb->row_ptr[k], re = pb->row_ptr[k + 1];
+        const int len = re - rs;
+        const int cmin = pb->cmin[k], cmax = pb->cmax[k];
+        int lower = 0, upper = 0;
+        for (int e = rs; e != re; ++e) {
+            if ((pb->factor ? pb->factor[e] : 1) > 0)
+                ++upper;
+            else
+                ++lower;
+        }
+        switch (kind) {
+        case BXH_EQ_01: // itm-solver-equalities-01.cpp:84-96
+            if (cmin != cmax)
+                return fail(BXH_ERR_INVALID, "equalities-01 needs min == max");
+            bmin[k] = bmax[k] = cmin;
+            break;
+        case BXH_INEQ_01: // itm-solver-inequalities-01.cpp:88-106
+            if (cmin == cmax) {
+                bmin[k] = cmin;
+                bmax[k] = cmax;
+            } else {
+                bmin[k] = std::max(0, cmin);
+                bmax[k] = std::min(len, cmax);
+            }
+            break;
+        case BXH_EQ_101: // itm-solver-equalities-101.cpp:98-113
+            if (cmin != cmax)
+                return fail(BXH_ERR_INVALID, "equalities-101 needs min == max");
+            bmin[k] = bmax[k] = cmin;
+            bneg[k] = lower;
+            break;
+        default: // itm-solver-inequalities-101.cpp:99-129
+            if (cmin == cmax) {
+                bmin[k] = cmin;
+                bmax[k] = cmax;
+            } else {
+                bmin[k] = std::max(-lower, cmin);
+                bmax[k] = std::min(upper, cmax);
+            }
+            bneg[k] = lower;
+            break;
+        }
+        if (bmin[k] > bmax[k])
+            return fail(BXH_ERR_INVALID, "constraint with min > max");
+    }
+
+    // ---- launch geometry ----------------------------------------------------
+    const bxh::LdsPlan lp =
+      bxh::lds_plan(m, h->nwords, rmax, static_cast<int>(h->fsize));
+    if (lp.total > 160 * 1024)
+        return fail(BXH_ERR_UNSUPPORTED,
+                    "instance does not fit the one-workgroup-per-instance "
+                    "kernel (pi, x and the row buffers must fit 160 KiB of "
+                    "LDS)");
+    h->lds_bytes = static_cast<size_t>(lp.total);
+    h->threads = std::min(1024, std::max(64, bxh::next_pow2(rmax)));
+
+    HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+
+    // ---- upload -------------------------------------------------------------
+    HIP_TRY(h->row_ptr.upload(std::vector<int>(pb->row_ptr, pb->row_ptr + m + 1)));
+    HIP_TRY(h->row_col.upload(std::vector<int>(pb->col, pb->col + nnz)));
+    HIP_TRY(h->row_pos.upload(row_pos));
+    HIP_TRY(h->col_ptr.upload(col_ptr));
+    HIP_TRY(h->col_row.upload(col_row));
+    HIP_TRY(h->bmin.upload(bmin));
+    HIP_TRY(h->bmax.upload(bmax));
+    HIP_TRY(h->bneg.upload(bneg));
+    HIP_TRY(h->fac_csr.upload(fac_csr));
+    HIP_TRY(h->fac_csc.upload(fac_csc));
+    {
+        std::vector<unsigned char> c;
+        if (float_type == BXH_FLOAT)
+            to_float<float>(pb->cost, n, c);
+        else
+            to_float<double>(pb->cost, n, c);
+        HIP_TRY(h->cost.upload(c));
+    }
+    h->h_row_pos = std::move(row_pos);
+    h->h_row_ptr.assign(pb->row_ptr, pb->row_ptr + m + 1);
+    h->h_col_ptr = std::move(col_ptr);
+    h->h_row_col.assign(pb->col, pb->col + nnz);
+
+    const size_t B = static_cast<size_t>(batch);
+    HIP_TRY(h->P.alloc(B * nnz * h->fsize));
+    HIP_TRY(h->pi.alloc(B * m * h->fsize));
+    HIP_TRY(h->rstale.alloc(B * (rmax + 1) * h->fsize));
+    HIP_TRY(h->x.alloc(B * 2 * h->nwords));
+    HIP_TRY(h->vlist.alloc(B * m));
+    HIP_TRY(h->vcount.alloc(B));
+    HIP_TRY(h->vflag.alloc(B * m));
+    HIP_TRY(h->status.alloc(B));
+    HIP_TRY(h->kappa.alloc(B));
+    HIP_TRY(h->active.alloc(B));
+    HIP_TRY(hipMemset(h->P.p, 0, B * nnz * h->fsize));
+    HIP_TRY(hipMemset(h->pi.p, 0, B * m * h->fsize));
+    HIP_TRY(hipMemset(h->rstale.p, 0, B * (rmax + 1) * h->fsize));
+    HIP_TRY(hipMemset(h->x.p, 0, B * 2 * h->nwords * sizeof(unsigned)));
+    HIP_TRY(hipMemset(h->vcount.p, 0, B * sizeof(int)));
+    HIP_TRY(hipMemset(h->status.p, 0, B * sizeof(bxh::DevStatus)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_status),
+                          B * sizeof(bxh::DevStatus),
+                          hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(
+      reinterpret_cast<void**>(&h->h_kappa), B * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(
+      reinterpret_cast<void**>(&h->h_active), B, hipHostMallocDefault));
+    {
+        // every worker's engine starts as minstd_rand0(1) until bxh_set_rng
+        std::vector<bxh::DevStatus> s(B);
+        for (auto& v : s) {
+            std::memset(&v, 0, sizeof v);
+            v.rng = 1;
+        }
+        HIP_TRY(hipMemcpy(h->status.p,
+                          s.data(),
+                          B * sizeof(bxh::DevStatus),
+                          hipMemcpyHostToDevice));
+    }
+
+    // the kernels may ask for more than the 64 KiB default dynamic LDS
+    if (lp.total > 64 * 1024) {
+#define BXH_SET_LDS(K)                                                         \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&K),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                lp.total))
+        BXH_SET_LDS((bxh::sweep_kernel<float, false>));
+        BXH_SET_LDS((bxh::sweep_kernel<float, true>));
+        BXH_SET_LDS((bxh::sweep_kernel<double, false>));
+        BXH_SET_LDS((bxh::sweep_kernel<double, true>));
+        BXH_SET_LDS((bxh::order_init_kernel<float>));
+        BXH_SET_LDS((bxh::order_init_kernel<double>));
+#undef BXH_SET_LDS
+    }
+
+    bxh::DevProblem& dp = h->dp;
+    dp.m = m;
+    dp.n = n;
+    dp.nnz = nnz;
+    dp.rmax = rmax;
+    dp.nwords = h->nwords;
+    dp.kind = kind;
+    dp.maximize = h->maximize;
+    dp.row_ptr = h->row_ptr.p;
+    dp.row_col = h->row_col.p;
+    dp.row_pos = h->row_pos.p;
+    dp.col_ptr = h->col_ptr.p;
+    dp.col_row = h->col_row.p;
+    dp.fac_csr = h->fac_csr.p;
+    dp.fac_csc = h->fac_csc.p;
+    dp.bmin = h->bmin.p;
+    dp.bmax = h->bmax.p;
+    dp.bneg = h->bneg.p;
+    dp.cost = h->cost.p;
+
+    bxh::DevState& ds = h->ds;
+    ds.P = h->P.p;
+    ds.pi = h->pi.p;
+    ds.x = h->x.p;
+    ds.rstale = h->rstale.p;
+    ds.vlist = h->vlist.p;
+    ds.vcount = h->vcount.p;
+    ds.vflag = h->vflag.p;
+    ds.status = h->status.p;
+
+    *out = guard.release();
+    return BXH_OK;
+}
+
+int
+bxh_destroy(bxh_handle h)
+{
+    if (!h)
+        return BXH_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+    return BXH_OK;
+}
+
+int
+bxh_set_stream(bxh_handle h, void* s)
+{
+    if (!h)
+        return fail(BXH_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->stream = s ? static_cast<hipStream_t>(s) : h->own_stream;
+    return BXH_OK;
+}
+
+int
+bxh_batch(bxh_handle h)
+{
+    return h ? h->batch : BXH_ERR_INVALID;
+}
+int
+bxh_nwords(bxh_handle h)
+{
+    return h ? h->nwords : BXH_ERR_INVALID;
+}
+int
+bxh_rmax(bxh_handle h)
+{
+    return h ? h->rmax : BXH_ERR_INVALID;
+}
+
+int
+bxh_set_x(bxh_handle h, int inst, const uint64_t* words)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->x.p + static_cast<size_t>(inst) * 2 * h->nwords,
+                      words,
+                      static_cast<size_t>(h->nwords) * 8,
+                      hipMemcpyHostToDevice));
+    return BXH_OK;
+}
+
+int
+bxh_get_x(bxh_handle h, int inst, uint64_t* words)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(words,
+                      h->x.p + static_cast<size_t>(inst) * 2 * h->nwords,
+                      static_cast<size_t>(h->nwords) * 8,
+                      hipMemcpyDeviceToHost));
+    return BXH_OK;
+}
+
+int
+bxh_set_pi(bxh_handle h, int inst, const double* v)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    return set_vec(h, h->pi.p + static_cast<size_t>(inst) * h->m * h->fsize, v, h->m);
+}
+
+int
+bxh_get_pi(bxh_handle h, int inst, double* v)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    return get_vec(h, h->pi.p + static_cast<size_t>(inst) * h->m * h->fsize, v, h->m);
+}
+
+int
+bxh_set_P(bxh_handle h, int inst, const double* v)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    std::vector<double> csc(static_cast<size_t>(h->nnz));
+    for (int e = 0; e != h->nnz; ++e)
+        csc[h->h_row_pos[e]] = v[e];
+    return set_vec(
+      h, h->P.p + static_cast<size_t>(inst) * h->nnz * h->fsize, csc.data(), h->nnz);
+}
+
+int
+bxh_get_P(bxh_handle h, int inst, double* v)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    std::vector<double> csc(static_cast<size_t>(h->nnz));
+    if (int rc = get_vec(h,
+                         h->P.p + static_cast<size_t>(inst) * h->nnz * h->fsize,
+                         csc.data(),
+                         h->nnz))
+        return rc;
+    for (int e = 0; e != h->nnz; ++e)
+        v[e] = csc[h->h_row_pos[e]];
+    return BXH_OK;
+}
+
+int
+bxh_set_rng(bxh_handle h, int inst, uint32_t state)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    if (state == 0 || state >= 2147483647u)
+        return fail(BXH_ERR_INVALID, "minstd_rand0 state must be in [1, 2^31-2]");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(&h->status.p[inst].rng, &state, 4, hipMemcpyHostToDevice));
+    return BXH_OK;
+}
+
+int
+bxh_get_rng(bxh_handle h, int inst, uint32_t* state)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(state, &h->status.p[inst].rng, 4, hipMemcpyDeviceToHost));
+    return BXH_OK;
+}
+
+int
+bxh_reset(bxh_handle h, int inst)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemset(h->P.p + static_cast<size_t>(inst) * h->nnz * h->fsize,
+                      0,
+                      static_cast<size_t>(h->nnz) * h->fsize));
+    HIP_TRY(hipMemset(h->pi.p + static_cast<size_t>(inst) * h->m * h->fsize,
+                      0,
+                      static_cast<size_t>(h->m) * h->fsize));
+    return BXH_OK;
+}
+
+int
+bxh_order_init(bxh_handle h, int order, int32_t* remaining)
+{
+    if (!h)
+        return fail(BXH_ERR_INVALID, "null handle");
+    if (order < BXH_ORDER_NONE || order > BXH_ORDER_RANDOM_SORTING)
+        return fail(BXH_ERR_UNSUPPORTED,
+                    "only none / reversing / random_sorting row orders are on "
+                    "the device yet");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->float_type == BXH_FLOAT)
+        hipLaunchKernelGGL((bxh::order_init_kernel<float>),
+                           dim3(h->batch),
+                           dim3(h->threads),
+                           h->lds_bytes,
+                           h->stream,
+                           h->dp,
+                           h->ds);
+    else
+        hipLaunchKernelGGL((bxh::order_init_kernel<double>),
+                           dim3(h->batch),
+                           dim3(h->threads),
+                           h->lds_bytes,
+                           h->stream,
+                           h->dp,
+                           h->ds);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (remaining)
+        HIP_TRY(hipMemcpy(remaining,
+                          h->vcount.p,
+                          static_cast<size_t>(h->batch) * sizeof(int),
+                          hipMemcpyDeviceToHost));
+    return BXH_OK;
+}
+
+int
+bxh_get_violated(bxh_handle h, int inst, int32_t* rows, int32_t* count)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int c = 0;
+    HIP_TRY(hipMemcpy(&c, h->vcount.p + inst, sizeof(int), hipMemcpyDeviceToHost));
+    if (count)
+        *count = c;
+    if (rows && c > 0)
+        HIP_TRY(hipMemcpy(rows,
+                          h->vlist.p + static_cast<size_t>(inst) * h->m,
+                          static_cast<size_t>(c) * sizeof(int),
+                          hipMemcpyDeviceToHost));
+    return BXH_OK;
+}
+
+int
+bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
+{
+    if (!h || !a || !a->kappa)
+        return fail(BXH_ERR_INVALID, "null argument");
+    if (a->order < BXH_ORDER_NONE || a->order > BXH_ORDER_RANDOM_SORTING)
+        return fail(BXH_ERR_UNSUPPORTED,
+                    "only none / reversing / random_sorting row orders are on "
+                    "the device yet");
+    for (int i = 0; i != h->batch; ++i)
+        if (!(a->kappa[i] >= 0.0 && a->kappa[i] < 1.0))
+            return fail(BXH_ERR_INVALID, "kappa must be in [0, 1)");
+    HIP_TRY(hipSetDevice(h->device));
+
+    // the pinned staging buffers are reused by the next call: wait for the
+    // previous upload to have been consumed
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::memcpy(h->h_kappa, a->kappa, static_cast<size_t>(h->batch) * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(h->kappa.p,
+                           h->h_kappa,
+                           static_cast<size_t>(h->batch) * sizeof(double),
+                           hipMemcpyHostToDevice,
+                           h->stream));
+    bxh::DevSweep s;
+    s.kappa = h->kappa.p;
+    s.delta = a->delta;
+    s.theta = a->theta;
+    s.obj_amp = a->obj_amp;
+    s.is_push = a->is_push;
+    s.order = a->order;
+    s.active = nullptr;
+    if (a->active) {
+        std::memcpy(h->h_active, a->active, static_cast<size_t>(h->batch));
+        HIP_TRY(hipMemcpyAsync(h->active.p,
+                               h->h_active,
+                               static_cast<size_t>(h->batch),
+                               hipMemcpyHostToDevice,
+                               h->stream));
+        s.active = h->active.p;
+    }
+    return h->float_type == BXH_FLOAT ? launch_sweep<float>(h, s)
+                                      : launch_sweep<double>(h, s);
+}
+
+int
+bxh_status_sync(bxh_handle h, bxh_status* out)
+{
+    if (!h)
+        return fail(BXH_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->h_status,
+                           h->status.p,
+                           static_cast<size_t>(h->batch) * sizeof(bxh::DevStatus),
+                           hipMemcpyDeviceToHost,
+                           h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (out) {
+        static_assert(sizeof(bxh_status) == sizeof(bxh::DevStatus), "ABI");
+        std::memcpy(out, h->h_status, static_cast<size_t>(h->batch) * sizeof(bxh_status));
+    }
+    return BXH_OK;
+}
+
+int
+bxh_sweep(bxh_handle h, const bxh_sweep_args* a, bxh_status* out)
+{
+    if (int rc = bxh_sweep_async(h, a))
+        return rc;
+    return bxh_status_sync(h, out);
+}
+
+int
+bxh_row_bytes(bxh_handle h, double* bytes_m)
+{
+    if (!h || !bytes_m)
+        return fail(BXH_ERR_INVALID, "null argument");
+    const double F = static_cast<double>(h->fsize);
+    for (int k = 0; k != h->m; ++k) {
+        const int rs = h->h_row_ptr[k], re = h->h_row_ptr[k + 1];
+        double b = 0.0;
+        for (int e = rs; e != re; ++e) {
+            const int j = h->h_row_col[e];
+            b += static_cast<double>(h->h_col_ptr[j + 1] - h->h_col_ptr[j]) * (4.0 + 2.0 * F);
+        }
+        const double r = static_cast<double>(re - rs);
+        b += r * (4.0 + 5.0 * F) + 2.0 * F + static_cast<double>((re - rs + 7) / 8) * 2.0;
+        bytes_m[k] = b;
+    }
+    return BXH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,558 @@
+// baryonyx_amd/csrc/bxh_kernels.hpp -- gfx950 kernels of the in-the-middle
+// row update (device side of include/bxh.h).
+//
+// One workgroup == one Solver instance (the reference runs one Solver per
+// worker thread, lib/src/itm-optimizer-common.hpp:649-653).  Rows of one
+// instance are strictly sequential (row k+1 reads the pi_k and P_k. written
+// by row k), so the parallelism is lanes-over-the-columns-of-a-row times
+// instances-per-GPU.
+//
+// Floating-point results must be bit-identical to the reference's, which
+// fixes the order of every sum: a lane walks ITS column in CSC order with two
+// separate accumulators exactly like compute_reduced_costs
+// (lib/src/itm-solver-inequalities-01.cpp:166-191).  Build with
+// -ffp-contract=off.
+//
+// Data layout in HBM: P is stored in CSC order so a column
+// walk reads one contiguous run; `row_pos[e]` maps CSR element e to its CSC
+// slot for the two row-shaped accesses (decay and affect).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bxh {
+
+struct DevProblem
+{
+    int m, n, nnz, rmax, nwords;
+    int kind;     // bxh_kind
+    int maximize; // 0 / 1
+    const int* row_ptr;        // [m+1]
+    const int* row_col;        // [nnz]   column of CSR element e
+    const int* row_pos;        // [nnz]   CSC slot of CSR element e
+    const int* col_ptr;        // [n+1]
+    const int* col_row;        // [nnz]   row of CSC slot q
+    const signed char* fac_csr; // [nnz]  coefficient of CSR element (101 kinds)
+    const signed char* fac_csc; // [nnz]  coefficient of CSC slot    (101 kinds)
+    const int* bmin;           // [m] clamped as the Solver constructor does
+    const int* bmax;           // [m]
+    const int* bneg;           // [m] negative_factor (== c_size of the row)
+    const void* cost;          // [n] Float
+};
+
+struct DevStatus // == bxh_status
+{
+    int remaining;
+    int pi_changed;
+    unsigned rng;
+    unsigned rows_in_sweep;
+    unsigned long long row_updates;
+};
+
+struct DevState
+{
+    void* P;             // [batch][nnz] Float, CSC order
+    void* pi;            // [batch][m]   Float
+    unsigned* x;         // [batch][2*nwords] u32 halves of the bit_array blocks
+    void* rstale;        // [batch][rmax+1] Float: R[].value as the reference's
+                         //   persistent R array holds it between rows
+    int* vlist;          // [batch][m] violated rows (compute_order::R)
+    int* vcount;         // [batch]
+    signed char* vflag;  // [batch][m] scratch
+    DevStatus* status;   // [batch]
+};
+
+struct DevSweep
+{
+    const double* kappa; // [batch]
+    double delta, theta, obj_amp;
+    int is_push;
+    int order;
+    const unsigned char* active; // [batch] or null
+};
+
+// ---------------------------------------------------------------------------
+// std::minstd_rand0 and the libstdc++ algorithms the reference calls on it
+// (itm-common.hpp:45,117-163).  Restated from GCC 11's <bits/random.h>,
+// <bits/uniform_int_dist.h> (the "2 divisions" downscaling branch -- the
+// engine's range is not 2^32-1) and <bits/stl_algo.h> std::shuffle.
+struct MinStd
+{
+    unsigned s;
+    __device__ unsigned next()
+    {
+        s = (unsigned)(((unsigned long long)s * 16807ull) % 2147483647ull);
+        return s;
+    }
+    // uniform_int_distribution<unsigned long>{0, urange}(g)
+    __device__ unsigned long long uniform(unsigned long long urange)
+    {
+        const unsigned long long urngrange = 2147483645ull; // max() - min()
+        // urange < urngrange always holds here (urange <= rmax^2 + rmax)
+        const unsigned long long uerange = urange + 1;
+        const unsigned long long scaling = urngrange / uerange;
+        const unsigned long long past = uerange * scaling;
+        unsigned long long ret;
+        do
+            ret = (unsigned long long)next() - 1ull;
+        while (ret >= past);
+        return ret / scaling;
+    }
+    // std::bernoulli_distribution(0.5)(g): generate_canonical<double,53> needs
+    // two draws of this engine (log2 of its range is 30).
+    __device__ bool coin()
+    {
+        const double r = 2147483646.0;
+        double sum = 0.0;
+        double tmp = 1.0;
+        sum += (double)(next() - 1u) * tmp;
+        tmp *= r;
+        sum += (double)(next() - 1u) * tmp;
+        tmp = 4611686009837453312.0; // double((long double)r * r)
+        double ret = sum / tmp;
+        if (ret >= 1.0)
+            ret = 0.99999999999999988897769753748434595763683319091796875;
+        return ret < 0.5;
+    }
+    // std::shuffle(first, first + len, g) on an int array.
+    template<typename Ptr>
+    __device__ void shuffle(Ptr a, unsigned len)
+    {
+        if (len < 2)
+            return;
+        auto swp = [&](unsigned i, unsigned j) {
+            int t = a[i];
+            a[i] = a[j];
+            a[j] = t;
+        };
+        const unsigned long long urngrange = 2147483645ull;
+        if (urngrange / len >= len) {
+            unsigned i = 1;
+            if ((len % 2) == 0) {
+                swp(i, (unsigned)uniform(1));
+                ++i;
+            }
+            while (i != len) {
+                const unsigned long long swap_range = (unsigned long long)i + 1;
+                const unsigned long long b1 = swap_range + 1;
+                const unsigned long long x = uniform(swap_range * b1 - 1);
+                swp(i, (unsigned)(x / b1));
+                ++i;
+                swp(i, (unsigned)(x % b1));
+                ++i;
+            }
+            return;
+        }
+        for (unsigned i = 1; i != len; ++i)
+            swp(i, (unsigned)uniform(i));
+    }
+};
+
+// ---------------------------------------------------------------------------
+template<typename Float>
+__device__ inline unsigned long long
+order_key(Float v, bool maximize)
+{
+    // Monotone map of the value to an unsigned key; -0.0 and +0.0 must be a
+    // tie, as `lhs.value < rhs.value` makes them (itm-common.hpp:139-144).
+    double d = (double)v;
+    if (d == 0.0)
+        d = 0.0;
+    unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    return maximize ? ~b : b;
+}
+
+// In-place bitonic sort of (key, id) pairs in LDS; n2 is a power of two.
+// All pairs are distinct (ids are), so the result is the unique sorted order:
+// "by value, ties by row-local id" -- the canonical tie rule of DESIGN.md.
+__device__ inline void
+bitonic_sort(unsigned long long* key, int* id, int n2)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool asc = (i & k) == 0;
+                const unsigned long long ka = key[i], kb = key[l];
+                const int ia = id[i], ib = id[l];
+                const bool gt = (ka > kb) || (ka == kb && ia > ib);
+                if (gt == asc) {
+                    key[i] = kb;
+                    key[l] = ka;
+                    id[i] = ib;
+                    id[l] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ inline int
+wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// compute_violated_constraints (itm-common.hpp:102-115): rebuild the ordered
+// list of rows whose activity is outside [bmin, bmax].  x is read from LDS.
+__device__ inline int
+rebuild_violated(const DevProblem& pb,
+                 const unsigned* x_s,
+                 signed char* vflag,
+                 int* vlist,
+                 int* scratch_s /* >= 64 ints */)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    const bool pm1 = pb.kind >= 2;
+
+    for (int k = wave; k < pb.m; k += nwaves) {
+        const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
+        int v = 0;
+        for (int e = rs + lane; e < re; e += 64) {
+            const int j = pb.row_col[e];
+            const int bit = (x_s[j >> 5] >> (j & 31)) & 1u;
+            v += pm1 ? (int)pb.fac_csr[e] * bit : bit;
+        }
+        v = wave_sum(v);
+        if (lane == 0)
+            vflag[k] = !(pb.bmin[k] <= v && v <= pb.bmax[k]);
+    }
+    __syncthreads(); // vflag is only read back by this workgroup (same CU)
+
+    int base = 0;
+    for (int c = 0; c < pb.m; c += T) {
+        const int k = c + tid;
+        const bool f = k < pb.m && vflag[k] != 0;
+        const unsigned long long mask = __ballot(f);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            scratch_s[wave] = __popcll(mask);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w = 0; w < nwaves; ++w) {
+            const int cw = scratch_s[w];
+            if (w < wave)
+                off += cw;
+            tot += cw;
+        }
+        if (f)
+            vlist[base + off + prefix] = k;
+        base += tot;
+        __syncthreads();
+    }
+    return base;
+}
+
+// LDS carve shared by the kernels (host computes the same sizes).
+struct LdsPlan
+{
+    int off_pi, off_x, off_val, off_key, off_id, off_stale, off_misc, total;
+};
+
+__host__ __device__ inline int
+next_pow2(int v)
+{
+    int p = 1;
+    while (p < v)
+        p <<= 1;
+    return p;
+}
+
+__host__ __device__ inline LdsPlan
+lds_plan(int m, int nwords, int rmax, int fsize)
+{
+    auto al = [](int v) { return (v + 15) & ~15; };
+    LdsPlan p;
+    int o = 0;
+    p.off_pi = o;
+    o = al(o + m * fsize);
+    p.off_x = o;
+    o = al(o + nwords * 8);
+    p.off_val = o;
+    o = al(o + rmax * fsize);
+    const int n2 = next_pow2(rmax < 2 ? 2 : rmax);
+    p.off_key = o;
+    o = al(o + n2 * 8);
+    p.off_id = o;
+    o = al(o + n2 * 4);
+    p.off_stale = o;
+    o = al(o + (rmax + 1) * fsize);
+    p.off_misc = o;
+    o = al(o + 96 * 4);
+    p.total = o;
+    return p;
+}
+
+// misc_s slots
+enum
+{
+    MS_SEL = 0,
+    MS_TIE = 1,
+    MS_PICH = 2,
+    MS_CNT = 3,
+    MS_D = 8,      // Float d (8 bytes reserved)
+    MS_WAVES = 16  // 64 ints of scratch
+};
+
+template<typename Float>
+__global__ __launch_bounds__(1024) void
+order_init_kernel(DevProblem pb, DevState st)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LdsPlan lp = lds_plan(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float));
+    unsigned* x_s = (unsigned*)(smem + lp.off_x);
+    int* misc_s = (int*)(smem + lp.off_misc);
+    const int inst = blockIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x;
+
+    const unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        x_s[i] = xg[i];
+    __syncthreads();
+
+    const int cnt = rebuild_violated(pb,
+                                     x_s,
+                                     st.vflag + (size_t)inst * pb.m,
+                                     st.vlist + (size_t)inst * pb.m,
+                                     misc_s + MS_WAVES);
+    if (tid == 0) {
+        st.vcount[inst] = cnt;
+        st.status[inst].remaining = cnt;
+    }
+}
+
+// One sweep of one instance: compute_order::run / push_and_run
+// (itm-common.hpp:682-880) around compute_update_row /
+// push_and_compute_update_row of the 01 and 101 solvers
+// (itm-solver-inequalities-01.cpp:208-296, -equalities-01.cpp:184-270,
+//  -equalities-101.cpp:208-307, -inequalities-101.cpp:250-347).
+template<typename Float, bool PM1>
+__global__ __launch_bounds__(1024) void
+sweep_kernel(DevProblem pb, DevState st, DevSweep a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int inst = blockIdx.x;
+    if (a.active && !a.active[inst])
+        return;
+
+    const LdsPlan lp = lds_plan(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float));
+    Float* pi_s = (Float*)(smem + lp.off_pi);
+    unsigned* x_s = (unsigned*)(smem + lp.off_x);
+    Float* val_s = (Float*)(smem + lp.off_val);
+    unsigned long long* key_s = (unsigned long long*)(smem + lp.off_key);
+    int* id_s = (int*)(smem + lp.off_id);
+    Float* stale_s = (Float*)(smem + lp.off_stale);
+    int* misc_s = (int*)(smem + lp.off_misc);
+    Float* d_s = (Float*)(misc_s + MS_D);
+
+    const int tid = threadIdx.x, T = blockDim.x;
+    const bool maximize = pb.maximize != 0;
+    const int kind = pb.kind;
+
+    Float* P = (Float*)st.P + (size_t)inst * pb.nnz;
+    Float* pig = (Float*)st.pi + (size_t)inst * pb.m;
+    unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
+    Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
+    int* vlist = st.vlist + (size_t)inst * pb.m;
+    const Float* cost = (const Float*)pb.cost;
+
+    const Float kappa = (Float)a.kappa[inst];
+    const Float delta = (Float)a.delta;
+    const Float theta = (Float)a.theta;
+    const Float obj_amp = (Float)a.obj_amp;
+    const bool push = a.is_push != 0;
+
+    for (int i = tid; i < pb.m; i += T)
+        pi_s[i] = pig[i];
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        x_s[i] = xg[i];
+    for (int i = tid; i <= pb.rmax; i += T)
+        stale_s[i] = staleg[i];
+
+    MinStd rng;
+    rng.s = st.status[inst].rng; // meaningful in thread 0 only
+    const int nrows = st.vcount[inst];
+
+    if (tid == 0) {
+        misc_s[MS_PICH] = 0;
+        // compute_order: random_sorting shuffles the list before the sweep
+        // (itm-common.hpp:708-714 / :817-823)
+        if (a.order == 2)
+            rng.shuffle(vlist, (unsigned)nrows);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < nrows; ++it) {
+        const int k = (a.order == 1) ? vlist[nrows - 1 - it] : vlist[it];
+        const int rs = pb.row_ptr[k];
+        const int r = pb.row_ptr[k + 1] - rs;
+
+        // ---- decrease_preference + compute_reduced_costs (+ push) ----------
+        for (int idx = tid; idx < r; idx += T) {
+            const int e = rs + idx;
+            const int j = pb.row_col[e];
+            const int pe = pb.row_pos[e];
+            Float sum_a_pi = 0;
+            Float sum_a_p = 0;
+            const int qe = pb.col_ptr[j + 1];
+            for (int q = pb.col_ptr[j]; q < qe; ++q) {
+                Float p = P[q];
+                if (q == pe)
+                    p = p * theta; // P[e] *= theta, written back by affect
+                const Float piv = pi_s[pb.col_row[q]];
+                if (PM1) {
+                    const Float fa = (Float)pb.fac_csc[q];
+                    sum_a_pi += fa * piv;
+                    sum_a_p += fa * p;
+                } else {
+                    sum_a_pi += piv;
+                    sum_a_p += p;
+                }
+            }
+            Float v = cost[j] - sum_a_pi - sum_a_p;
+            if (PM1 && pb.fac_csr[e] < 0)
+                v = -v;
+            if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
+                v += obj_amp * (PM1 ? cost[j] : cost[idx]);
+            val_s[idx] = v;
+        }
+        const int n2 = next_pow2(r < 2 ? 2 : r);
+        if (tid == 0)
+            misc_s[MS_TIE] = 0;
+        __syncthreads();
+
+        // ---- calculator_sort: sort, then shuffle every run of equal values -
+        for (int i = tid; i < n2; i += T) {
+            key_s[i] = i < r ? order_key<Float>(val_s[i], maximize) : ~0ull;
+            id_s[i] = i;
+        }
+        __syncthreads();
+        if (r > 1)
+            bitonic_sort(key_s, id_s, n2);
+        for (int i = tid; i + 1 < r; i += T)
+            if (key_s[i] == key_s[i + 1])
+                misc_s[MS_TIE] = 1;
+        __syncthreads();
+
+        // ---- thread 0: tie shuffle, select_variables, pi and d of affect ---
+        if (tid == 0) {
+            if (misc_s[MS_TIE]) {
+                int b0 = 0;
+                for (int i = 1; i <= r; ++i) {
+                    if (i == r || key_s[i] != key_s[b0]) {
+                        rng.shuffle(id_s + b0, (unsigned)(i - b0));
+                        b0 = i;
+                    }
+                }
+            }
+
+            auto Rv = [&](int i) -> Float { // R[i].value, R[r] is stale
+                return i < r ? val_s[id_s[i]] : stale_s[i];
+            };
+            auto stop = [&](Float v) -> bool { // itm-common.hpp:150-163
+                if (v == 0)
+                    return rng.coin();
+                return maximize ? v < 0 : v > 0;
+            };
+
+            const int c_size = PM1 ? pb.bneg[k] : 0;
+            int bkmin = pb.bmin[k], bkmax = pb.bmax[k];
+            int sel;
+            if (kind == 0 || kind == 2 || bkmin == bkmax) {
+                sel = min(bkmin + c_size, r) - 1;
+            } else {
+                if (kind == 1) {
+                    bkmin = min(bkmin, r);
+                    bkmax = min(bkmax, r);
+                } else {
+                    bkmin += c_size;
+                    bkmax = min(bkmax + c_size, r);
+                }
+                sel = bkmax - 1;
+                for (int i = bkmin; i <= bkmax; ++i)
+                    if (stop(Rv(i))) {
+                        sel = i - 1;
+                        break;
+                    }
+            }
+
+            // affect, itm-common.hpp:393-436
+            const Float one = 1, two = 2;
+            const Float middle = (two + one) / two;
+            Float d = delta;
+            if (sel < 0) {
+                d += (kappa / (one - kappa)) * (Rv(0) / two);
+            } else if (sel + 1 >= r) {
+                d += (kappa / (one - kappa)) * (Rv(sel) * middle);
+            } else {
+                const Float old_pi = pi_s[k];
+                const Float new_pi = old_pi + ((Rv(sel) + Rv(sel + 1)) / two);
+                pi_s[k] = new_pi;
+                d += (kappa / (one - kappa)) * (Rv(sel + 1) - Rv(sel));
+                if (signbit(old_pi) != signbit(new_pi))
+                    misc_s[MS_PICH] = 1;
+            }
+            misc_s[MS_SEL] = sel;
+            *d_s = d;
+        }
+        __syncthreads();
+
+        // ---- affect: x bits and P of the row, by sorted position -----------
+        {
+            const int sel = misc_s[MS_SEL];
+            const Float d = *d_s;
+            for (int i = tid; i < r; i += T) {
+                const int idx = id_s[i];
+                const int e = rs + idx;
+                const int j = pb.row_col[e];
+                const int pe = pb.row_pos[e];
+                bool up = i <= sel; // sel < 0: none; sel + 1 >= r: all
+                if (PM1 && pb.fac_csr[e] < 0)
+                    up = !up;
+                const Float p = P[pe] * theta;
+                if (up) {
+                    atomicOr(&x_s[j >> 5], 1u << (j & 31));
+                    P[pe] = p + d;
+                } else {
+                    atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
+                    P[pe] = p - d;
+                }
+                stale_s[i] = val_s[idx]; // R[i].value after the sort
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write back, then compute_violated_constraints ---------------------
+    for (int i = tid; i < pb.m; i += T)
+        pig[i] = pi_s[i];
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        xg[i] = x_s[i];
+    for (int i = tid; i <= pb.rmax; i += T)
+        staleg[i] = stale_s[i];
+
+    const int cnt = rebuild_violated(
+      pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES);
+
+    if (tid == 0) {
+        st.vcount[inst] = cnt;
+        DevStatus s = st.status[inst];
+        s.remaining = cnt;
+        s.pi_changed = misc_s[MS_PICH];
+        s.rng = rng.s;
+        s.rows_in_sweep = (unsigned)nrows;
+        s.row_updates += (unsigned long long)nrows;
+        st.status[inst] = s;
+    }
+}
+
+} // namespace bxh

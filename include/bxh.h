@@ -1,0 +1,175 @@
+/* include/bxh.h -- C ABI of the MI355X device layer for baryonyx's
+ * in-the-middle row update.
+ *
+ * The reference has no FFI: the seam is its duck-typed C++ *Solver concept*
+ * (SURVEY.md 8(b)-2), i.e. what `compute_order::run / push_and_run`
+ * (lib/src/itm-common.hpp:682-880), `solver_functor`
+ * (lib/src/itm-solver-common.hpp:63-225) and `optimize_functor`
+ * (lib/src/itm-optimizer-common.hpp:603-753) call on a solver object.  Each
+ * entry point below names the reference interface it stands in for.  One
+ * handle == a batch of `batch` independent Solver instances over ONE
+ * constraint matrix (the reference builds one Solver per worker thread,
+ * itm-optimizer-common.hpp:649-653).
+ *
+ * Conventions: every function returns 0 or a negative bxh_error; no C++
+ * exception crosses the ABI; a handle is used by one host thread at a time
+ * (the rule `baryonyx::context` has, lib/include/baryonyx/core:483-489); host
+ * buffers are owned by the caller; all device memory is owned by the handle.
+ * Floating-point state crosses the boundary as double (exact for both device
+ * float kinds).
+ */
+#ifndef BXH_H
+#define BXH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bxh_handle_s* bxh_handle;
+
+enum bxh_error
+{
+    BXH_OK = 0,
+    BXH_ERR_INVALID = -1,     /* bad argument                                */
+    BXH_ERR_OOM = -2,         /* -> solver_failure(not_enough_memory),
+                                 lib/include/baryonyx/core:258-263            */
+    BXH_ERR_UNSUPPORTED = -3, /* valid in the reference, not on the device yet */
+    BXH_ERR_DEVICE = -4       /* HIP runtime error (see bxh_last_error)       */
+};
+
+/* Solver family == which itm-solver-*.cpp the handle replaces. */
+enum bxh_kind
+{
+    BXH_EQ_01 = 0,    /* itm-solver-equalities-01.cpp    */
+    BXH_INEQ_01 = 1,  /* itm-solver-inequalities-01.cpp  */
+    BXH_EQ_101 = 2,   /* itm-solver-equalities-101.cpp   */
+    BXH_INEQ_101 = 3, /* itm-solver-inequalities-101.cpp */
+    BXH_INEQ_Z = 4    /* itm-solver-inequalities-Z.cpp   */
+};
+
+/* floating_point_type, lib/include/baryonyx/core:340-345 (long double has no
+ * device form -> BXH_ERR_UNSUPPORTED). */
+enum bxh_float
+{
+    BXH_FLOAT = 0,
+    BXH_DOUBLE = 1
+};
+
+/* solver_parameters::constraint_order, lib/include/baryonyx/core:347-358 */
+enum bxh_order
+{
+    BXH_ORDER_NONE = 0,
+    BXH_ORDER_REVERSING = 1,
+    BXH_ORDER_RANDOM_SORTING = 2,
+    BXH_ORDER_INFEASIBILITY_DECR = 3,
+    BXH_ORDER_INFEASIBILITY_INCR = 4,
+    BXH_ORDER_LAGRANGIAN_DECR = 5,
+    BXH_ORDER_LAGRANGIAN_INCR = 6,
+    BXH_ORDER_PI_SIGN_CHANGE = 7,
+    BXH_ORDER_CYCLE = 8
+};
+
+/* What a Solver constructor receives: `std::vector<merged_constraint>` in CSR
+ * form (lib/src/itm-common.hpp:55-71) and the NORMALISED cost functor
+ * (`norm_costs`, itm-solver-common.hpp:76-77).  The handle builds the CSC
+ * view itself, as `sparse_matrix<int>` does (lib/src/sparse-matrix.hpp:86-186),
+ * and clamps the bounds per solver kind as each constructor does. */
+typedef struct bxh_problem
+{
+    int32_t m;              /* merged constraints                           */
+    int32_t n;              /* variables                                    */
+    int64_t nnz;            /* elements                                     */
+    const int32_t* row_ptr; /* [m+1]                                        */
+    const int32_t* col;     /* [nnz] variable_index, constraint order       */
+    const int32_t* factor;  /* [nnz] coefficient; NULL = all +1             */
+    const int32_t* cmin;    /* [m] merged_constraint::min                   */
+    const int32_t* cmax;    /* [m] merged_constraint::max                   */
+    const double* cost;     /* [n] normalised linear cost, already rounded
+                                    to the device float kind                */
+    int32_t n_quad;         /* quadratic cost terms (must be 0 for now)     */
+    const int32_t* q_ptr;   /* [n+1]   quadratic_cost_type::indices         */
+    const int32_t* q_id;    /* [n_quad]                                     */
+    const double* q_factor; /* [n_quad]                                     */
+} bxh_problem;
+
+/* Arguments of one sweep of every instance == one call of
+ * compute_order::run (itm-common.hpp:800-880) or, with is_push,
+ * compute_order::push_and_run (:682-798). */
+typedef struct bxh_sweep_args
+{
+    const double* kappa;   /* [batch] per-instance kappa                    */
+    double delta;
+    double theta;
+    double obj_amp;        /* objective amplifier (push only)               */
+    int32_t is_push;
+    int32_t order;         /* bxh_order                                     */
+    const uint8_t* active; /* [batch] 0 = skip this instance; NULL = all    */
+} bxh_sweep_args;
+
+/* Per-instance outcome of a sweep (`remaining` is what run() returns). */
+typedef struct bxh_status
+{
+    int32_t remaining;    /* violated constraints after the sweep           */
+    int32_t pi_changed;   /* OR of affect()'s sign-change results           */
+    uint32_t rng;         /* minstd_rand0 state after the sweep             */
+    uint32_t rows_in_sweep;
+    uint64_t row_updates; /* cumulative count of row-loop bodies executed   */
+} bxh_status;
+
+const char* bxh_last_error(void);
+
+/* Solver constructors (e.g. itm-solver-inequalities-01.cpp:72-107), `batch`
+ * of them, on HIP device `device`. P and pi start at zero, x at zero. */
+int bxh_create(const bxh_problem* pb,
+               int kind,
+               int float_type,
+               int maximize,
+               int batch,
+               int device,
+               bxh_handle* out);
+int bxh_destroy(bxh_handle h);
+
+/* Launch stream (a hipStream_t, e.g. torch's current stream); NULL = the
+ * handle's own stream. */
+int bxh_set_stream(bxh_handle h, void* hip_stream);
+int bxh_batch(bxh_handle h);
+int bxh_nwords(bxh_handle h); /* bit_array block count n/64 + 1, bit-array.hpp:60-66 */
+int bxh_rmax(bxh_handle h);
+
+/* Solver fields x / pi / P (P in CSR element order, as `slv.P[e]`), and the
+ * worker's random engine. `inst` in [0, batch). */
+int bxh_set_x(bxh_handle h, int inst, const uint64_t* words);
+int bxh_get_x(bxh_handle h, int inst, uint64_t* words);
+int bxh_set_pi(bxh_handle h, int inst, const double* pi_m);
+int bxh_get_pi(bxh_handle h, int inst, double* pi_m);
+int bxh_set_P(bxh_handle h, int inst, const double* P_nnz);
+int bxh_get_P(bxh_handle h, int inst, double* P_nnz);
+int bxh_set_rng(bxh_handle h, int inst, uint32_t state);
+int bxh_get_rng(bxh_handle h, int inst, uint32_t* state);
+/* Solver::reset() (e.g. itm-solver-inequalities-01.cpp:109-113) */
+int bxh_reset(bxh_handle h, int inst);
+
+/* compute_order::init (itm-common.hpp:660-680): rebuild every instance's
+ * violated-row list from its current x; remaining[] may be NULL. */
+int bxh_order_init(bxh_handle h, int order, int32_t* remaining_batch);
+/* the current list (compute_order::R) of one instance */
+int bxh_get_violated(bxh_handle h, int inst, int32_t* rows_m, int32_t* count);
+
+/* One sweep of all active instances; blocks until the status is on the host. */
+int bxh_sweep(bxh_handle h, const bxh_sweep_args* args, bxh_status* status_batch);
+/* Same without the final synchronisation / copy: for back-to-back launches. */
+int bxh_sweep_async(bxh_handle h, const bxh_sweep_args* args);
+int bxh_status_sync(bxh_handle h, bxh_status* status_batch);
+
+/* Algorithmic bytes of one row update of row k:
+ * sum_{j in row k} c_j (4 + 2F) + r_k (4 + 5F) + 2F + ceil(r_k / 8) 2,
+ * summed over the rows of the last sweep per instance is reported by bench.py;
+ * this returns the per-row table so the host can do that sum. */
+int bxh_row_bytes(bxh_handle h, double* bytes_m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

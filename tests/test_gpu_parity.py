@@ -1,0 +1,79 @@
+"""-m gpu: the HIP row update (through the C ABI) against the CPU oracle, sweep
+by sweep, on the same seeded inputs.  Bit-exact on x / violated rows /
+remaining / RNG state, and -- because the kernel keeps the reference's
+summation order -- bit-exact on pi and P too (tolerance 0; north_star allows
+1e-6 relative)."""
+import numpy as np
+import pytest
+
+from baryonyx_amd import synth
+from helpers import bits_equal, first_diff, random_x
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (name, maker, float_type, maximize, order, x0_density)
+    ("scp-real-f64", lambda: synth.make_scp(60, 400, 0.06, "real", 11), 1, False, 0, 0.0),
+    ("scp-int-f64", lambda: synth.make_scp(60, 400, 0.06, "int", 12), 1, False, 0, 0.0),
+    ("scp-int-f32", lambda: synth.make_scp(60, 400, 0.06, "int", 13), 0, False, 0, 0.02),
+    ("scp-real-rev", lambda: synth.make_scp(50, 300, 0.08, "real", 14), 1, False, 1, 0.01),
+    ("scp-int-rand", lambda: synth.make_scp(50, 300, 0.08, "int", 15), 1, False, 2, 0.01),
+    ("scp-int-max", lambda: synth.make_scp(50, 300, 0.08, "int", 16), 1, True, 0, 0.5),
+    ("spp-int-f64", lambda: synth.make_spp(40, 300, 0.06, "int", 17), 1, False, 0, 0.0),
+    ("spp-real-f32", lambda: synth.make_spp(40, 300, 0.06, "real", 18), 0, False, 0, 0.05),
+    ("pm1-ineq-int", lambda: synth.make_pm1(50, 250, 0.06, "int", 19), 1, False, 0, 0.1),
+    ("pm1-ineq-real-max", lambda: synth.make_pm1(50, 250, 0.06, "real", 20), 1, True, 0, 0.3),
+    ("pm1-eq-int", lambda: synth.make_pm1(40, 250, 0.06, "int", 21, equalities=True), 1, False, 0, 0.1),
+    ("pm1-eq-real-f32", lambda: synth.make_pm1(40, 250, 0.06, "real", 22, equalities=True), 0, False, 2, 0.1),
+    ("c1-scp41-shaped", lambda: synth.config_c1("int"), 1, False, 0, 0.0),
+]
+
+
+def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweeps=12, push_at=(5, 9)):
+    theta = 0.5
+    orcs = []
+    for b in range(batch):
+        s = oracle.Solver(inst, float_type=float_type, sort_mode=1, cost_norm=4,
+                          seed=1000 + b, maximize=maximize)
+        orcs.append(s)
+    cost = orcs[0].cost()
+    delta = orcs[0].compute_delta(theta)
+    dev = bxh.DeviceBatch(inst, cost, batch, float_type=float_type, maximize=maximize)
+    assert dev.rmax == orcs[0].rmax
+
+    for b, s in enumerate(orcs):
+        x0 = random_x(inst.n, x0p, 77 + b) if x0p > 0 else np.zeros(s.nwords, np.uint64)
+        s.set_x(x0)
+        dev.set_x(b, x0)
+        dev.set_rng(b, s.rng)
+        s.order_init(order)
+    rem = dev.order_init(order)
+    for b, s in enumerate(orcs):
+        assert np.array_equal(dev.violated(b), s.violated()), f"initial violated list, inst {b}"
+        assert rem[b] == len(s.violated())
+
+    kappa = np.array([0.0 + 0.01 * b for b in range(batch)])
+    for it in range(sweeps):
+        push = it in push_at
+        amp = 5.0 if push else 0.0
+        st = dev.sweep(kappa, delta, theta, is_push=push, obj_amp=amp, order=order)
+        for b, s in enumerate(orcs):
+            r = s.sweep(float(kappa[b]), delta, theta, is_push=push, obj_amp=amp)
+            tag = f"sweep {it} inst {b}"
+            assert st["remaining"][b] == r, tag
+            assert np.array_equal(dev.get_x(b), s.get_x()), tag + " x"
+            assert np.array_equal(dev.violated(b), s.violated()), tag + " violated"
+            pd, po = dev.get_pi(b), s.get_pi()
+            assert bits_equal(pd, po), f"{tag} pi first diff at {first_diff(pd, po)}"
+            Pd, Po = dev.get_P(b), s.get_P()
+            assert bits_equal(Pd, Po), f"{tag} P first diff at {first_diff(Pd, Po)}"
+            assert st["rng"][b] == s.rng, tag + " rng"
+            assert st["row_updates"][b] == s.row_updates, tag + " row_updates"
+        kappa = kappa + 0.02
+    dev.close()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_sweeps_match_oracle(oracle, bxh, case):
+    _, maker, float_type, maximize, order, x0p = case
+    run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
