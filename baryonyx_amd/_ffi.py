@@ -33,7 +33,7 @@ SYMBOLS = [
     "bxh_nwords", "bxh_rmax", "bxh_set_x", "bxh_get_x", "bxh_set_pi", "bxh_get_pi",
     "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset",
     "bxh_order_init", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
-    "bxh_status_sync", "bxh_row_bytes",
+    "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time",
 ]
 
 
@@ -74,6 +74,7 @@ class BxhStatus(C.Structure):
         ("rng", C.c_uint32),
         ("rows_in_sweep", C.c_uint32),
         ("row_updates", C.c_uint64),
+        ("alg_bytes", C.c_double),
     ]
 
 
@@ -84,6 +85,7 @@ STATUS_DTYPE = np.dtype(
         ("rng", np.uint32),
         ("rows_in_sweep", np.uint32),
         ("row_updates", np.uint64),
+        ("alg_bytes", np.float64),
     ]
 )
 
@@ -143,6 +145,7 @@ def lib():
         L.bxh_sweep_async.argtypes = [C.c_void_p, C.POINTER(BxhSweepArgs)]
         L.bxh_status_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.bxh_row_bytes.argtypes = [C.c_void_p, f64p]
+        L.bxh_kernel_time.argtypes = [C.c_void_p, f64p, u64p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -287,6 +290,13 @@ class DeviceBatch:
     def status(self):
         _check(self.L.bxh_status_sync(self.h, self._status.ctypes.data_as(C.c_void_p)))
         return self._status.copy()
+
+    def kernel_time(self, reset=False):
+        """(total ms, launches) of the sweep kernels, from HIP events."""
+        ms = C.c_double()
+        n = C.c_uint64()
+        _check(self.L.bxh_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
 
     def row_bytes(self):
         b = np.zeros(self.inst.m, np.float64)

@@ -81,6 +81,7 @@ struct bxh_handle_s
     DevBuf<int> row_ptr, row_col, row_pos, col_ptr, col_row, bmin, bmax, bneg;
     DevBuf<signed char> fac_csr, fac_csc;
     DevBuf<unsigned char> cost; // Float[n]
+    DevBuf<double> row_bytes;   // [m]
     // host copies needed for state import/export and accounting
     std::vector<int> h_row_pos, h_row_ptr, h_col_ptr, h_row_col;
 
@@ -92,6 +93,12 @@ struct bxh_handle_s
     DevBuf<bxh::DevStatus> status;
     DevBuf<double> kappa;
     DevBuf<unsigned char> active;
+
+    // HIP events around every sweep kernel launch (bxh_kernel_time)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    double kernel_ms = 0.0;
+    unsigned long long kernel_launches = 0;
 
     bxh::DevStatus* h_status = nullptr; // pinned
     double* h_kappa = nullptr;          // pinned
@@ -108,6 +115,10 @@ struct bxh_handle_s
             (void)hipHostFree(h_kappa);
         if (h_active)
             (void)hipHostFree(h_active);
+        for (auto& ev : events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
         if (own_stream)
             (void)hipStreamDestroy(own_stream);
     }
@@ -173,11 +184,33 @@ get_vec(bxh_handle h, const unsigned char* src, double* dst, size_t n)
     return BXH_OK;
 }
 
+// Fold the finished event pairs into the running kernel time; the stream
+// must be idle.
+int
+drain_events(bxh_handle h)
+{
+    for (size_t i = 0; i != h->events_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+        h->kernel_ms += static_cast<double>(ms);
+        ++h->kernel_launches;
+    }
+    h->events_used = 0;
+    return BXH_OK;
+}
+
 template<typename Float>
 int
 launch_sweep(bxh_handle h, const bxh::DevSweep& a)
 {
     const bool pm1 = h->kind == BXH_EQ_101 || h->kind == BXH_INEQ_101;
+    if (h->events_used == h->events.size()) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        h->events.emplace_back(e0, e1);
+    }
+    HIP_TRY(hipEventRecord(h->events[h->events_used].first, h->stream));
     if (pm1)
         hipLaunchKernelGGL((bxh::sweep_kernel<Float, true>),
                            dim3(h->batch),
@@ -197,6 +230,8 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
                            h->ds,
                            a);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->events[h->events_used].second, h->stream));
+    ++h->events_used;
     return BXH_OK;
 }
 
@@ -393,6 +428,12 @@ bxh_create(const bxh_problem* pb,
     h->h_row_ptr.assign(pb->row_ptr, pb->row_ptr + m + 1);
     h->h_col_ptr = std::move(col_ptr);
     h->h_row_col.assign(pb->col, pb->col + nnz);
+    {
+        std::vector<double> rb(static_cast<size_t>(m));
+        if (int rc = bxh_row_bytes(h, rb.data()))
+            return rc;
+        HIP_TRY(h->row_bytes.upload(rb));
+    }
 
     const size_t B = static_cast<size_t>(batch);
     HIP_TRY(h->P.alloc(B * nnz * h->fsize));
@@ -465,6 +506,7 @@ bxh_create(const bxh_problem* pb,
     dp.bmax = h->bmax.p;
     dp.bneg = h->bneg.p;
     dp.cost = h->cost.p;
+    dp.row_bytes = h->row_bytes.p;
 
     bxh::DevState& ds = h->ds;
     ds.P = h->P.p;
@@ -498,6 +540,8 @@ bxh_set_stream(bxh_handle h, void* s)
         return fail(BXH_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = drain_events(h))
+        return rc;
     h->stream = s ? static_cast<hipStream_t>(s) : h->own_stream;
     return BXH_OK;
 }
@@ -696,6 +740,8 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
     // the pinned staging buffers are reused by the next call: wait for the
     // previous upload to have been consumed
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = drain_events(h))
+        return rc;
     std::memcpy(h->h_kappa, a->kappa, static_cast<size_t>(h->batch) * sizeof(double));
     HIP_TRY(hipMemcpyAsync(h->kappa.p,
                            h->h_kappa,
@@ -735,6 +781,8 @@ bxh_status_sync(bxh_handle h, bxh_status* out)
                            hipMemcpyDeviceToHost,
                            h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = drain_events(h))
+        return rc;
     if (out) {
         static_assert(sizeof(bxh_status) == sizeof(bxh::DevStatus), "ABI");
         std::memcpy(out, h->h_status, static_cast<size_t>(h->batch) * sizeof(bxh_status));
@@ -748,6 +796,26 @@ bxh_sweep(bxh_handle h, const bxh_sweep_args* a, bxh_status* out)
     if (int rc = bxh_sweep_async(h, a))
         return rc;
     return bxh_status_sync(h, out);
+}
+
+int
+bxh_kernel_time(bxh_handle h, double* total_ms, uint64_t* launches, int reset)
+{
+    if (!h)
+        return fail(BXH_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = drain_events(h))
+        return rc;
+    if (total_ms)
+        *total_ms = h->kernel_ms;
+    if (launches)
+        *launches = h->kernel_launches;
+    if (reset) {
+        h->kernel_ms = 0.0;
+        h->kernel_launches = 0;
+    }
+    return BXH_OK;
 }
 
 int

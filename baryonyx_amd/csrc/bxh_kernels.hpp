@@ -39,6 +39,7 @@ struct DevProblem
     const int* bmax;           // [m]
     const int* bneg;           // [m] negative_factor (== c_size of the row)
     const void* cost;          // [n] Float
+    const double* row_bytes;   // [m] algorithmic bytes of one update of row k
 };
 
 struct DevStatus // == bxh_status
@@ -48,6 +49,7 @@ struct DevStatus // == bxh_status
     unsigned rng;
     unsigned rows_in_sweep;
     unsigned long long row_updates;
+    double alg_bytes; // cumulative algorithmic bytes of the rows updated
 };
 
 struct DevState
@@ -381,6 +383,7 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
     MinStd rng;
     rng.s = st.status[inst].rng; // meaningful in thread 0 only
     const int nrows = st.vcount[inst];
+    double alg_bytes = 0.0; // thread 0 only
 
     if (tid == 0) {
         misc_s[MS_PICH] = 0;
@@ -445,6 +448,7 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
 
         // ---- thread 0: tie shuffle, select_variables, pi and d of affect ---
         if (tid == 0) {
+            alg_bytes += pb.row_bytes[k];
             if (misc_s[MS_TIE]) {
                 int b0 = 0;
                 for (int i = 1; i <= r; ++i) {
@@ -551,6 +555,7 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
         s.rng = rng.s;
         s.rows_in_sweep = (unsigned)nrows;
         s.row_updates += (unsigned long long)nrows;
+        s.alg_bytes += alg_bytes;
         st.status[inst] = s;
     }
 }

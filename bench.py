@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- row-updates/s of the in-the-middle inner loop on scpnrh-shaped
+instances (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A *step* is one sweep (compute_order::run / push_and_run,
+lib/src/itm-common.hpp:682-880) of every solver instance of the rank's batch,
+under the restart driver that mirrors optimize_functor
+(lib/src/itm-optimizer-common.hpp:620-752).  Workload at every N (weak
+scaling: fixed per-GPU work): BASELINE.json configs[1], an scpnrh1-shaped
+synthetic set-covering instance (1000 x 10000, 5 % density, inequalities-01
+path), 64 restarts per GPU; restarts are sharded over ranks with no data-path
+collective, the incumbent objective is min-reduced over RCCL at the end.
+
+Rank 0 prints ONE JSON line (see the task contract) with the extra objects
+  roofline     -- algorithmic bytes (SURVEY.md 8(d) formula) / sweep-kernel
+                  time from HIP events on the launch stream, vs 8 TB/s HBM
+  cpu_baseline -- the CPU oracle (a port of the reference path) timed on this
+                  host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="restarts per GPU")
+    ap.add_argument("--float", dest="float_kind", choices=["double", "float"], default="double")
+    ap.add_argument("--cost-kind", choices=["int", "real"], default="int")
+    ap.add_argument("--config", choices=["c1", "c2", "c3"], default="c2")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="wall budget of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    return ap.parse_args()
+
+
+def make_instance(args):
+    from baryonyx_amd import synth
+
+    return {"c1": synth.config_c1, "c2": synth.config_c2, "c3": synth.config_c3}[args.config](
+        args.cost_kind
+    )
+
+
+def cpu_baseline(inst, params, float_type, seconds, threads):
+    """Time the oracle's solve loop shape on host cores: every thread runs its
+    own Solver (own seed) from the Bastert start, sweep after sweep with the
+    same kappa schedule, for ~`seconds` of wall time."""
+    from oracle import oracle_ffi as O
+    from baryonyx_amd.driver import compute_delta
+
+    nthreads = threads if threads > 0 else (os.cpu_count() or 1)
+    totals = [0] * nthreads
+    sweeps = [0] * nthreads
+    stop_at = time.perf_counter() + seconds
+
+    def work(t):
+        s = O.Solver(inst, float_type=float_type, sort_mode=1, cost_norm=4, seed=1000 + t)
+        delta = s.compute_delta(params.theta)
+        s.set_x(np.zeros(s.nwords, np.uint64))
+        s.order_init(params.order)
+        kappa, i = params.kappa_min + 0.02 * 0.6, 0
+        while time.perf_counter() < stop_at:
+            r = s.sweep(kappa, delta, params.theta)
+            sweeps[t] += 1
+            if r == 0 or kappa > params.kappa_max or i >= params.limit:
+                # restart like the driver does: keep P / pi, raise kappa start
+                kappa, i = params.kappa_min + 0.04 * 0.6, 0
+                x = s.get_x()
+                x[:] = 0
+                s.set_x(x)
+                s.order_init(params.order)
+                continue
+            if i > params.w:
+                kappa += params.kappa_step * (r / inst.m) ** params.alpha
+            i += 1
+        totals[t] = s.row_updates
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    dt = time.perf_counter() - t0
+    return {
+        "value": sum(totals) / dt,
+        "unit": "row-updates/s",
+        "cores": nthreads,
+        "kind": "port",
+        "sample": f"{nthreads} oracle Solver threads x {dt:.1f}s of sweeps on the same "
+                  f"instance from the Bastert start ({sum(sweeps)} sweeps, {sum(totals)} row updates)",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from baryonyx_amd import _ffi
+    from baryonyx_amd.driver import Params, RestartPool, compute_delta, normalize_costs
+
+    float_type = 1 if args.float_kind == "double" else 0
+    F = 8 if float_type else 4
+    inst = make_instance(args)
+    params = Params()
+    cost = normalize_costs(inst.dense_costs(), params.cost_norm, float_type)
+    delta = compute_delta(cost, params.theta, float_type)
+
+    dev = _ffi.DeviceBatch(inst, cost, args.batch, float_type=float_type, device=local_rank)
+    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+    pool = RestartPool(dev, inst, params, float_type, seed=1 + rank)
+    pool.set_delta(delta)
+    dev.order_init(params.order)
+    scan_bytes = inst.nnz * 4 + inst.nnz / 8  # violated-row scan, per instance and sweep
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pool.step(record_objective=False)
+    barrier()
+    dev.kernel_time(reset=True)
+    bytes0 = float(dev.status()["alg_bytes"].sum())
+    rows_total = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows, st = pool.step(record_objective=False)
+        rows_total += rows
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = dev.kernel_time()
+    bytes1 = float(dev.status()["alg_bytes"].sum())
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    rows_t = torch.tensor([float(rows_total)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rows_t, op=dist.ReduceOp.SUM)
+    dt_max = float(tmax.item())
+    rows_all = float(rows_t.item())
+
+    # incumbent objective after the timed region: min over all restarts, then
+    # allreduce(min) over ranks (RCCL over xGMI)
+    best = np.inf
+    st = dev.status()
+    for b in range(args.batch):
+        if st["remaining"][b] == 0:
+            best = min(best, pool.objective(b))
+    best_t = torch.tensor([best], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(best_t, op=dist.ReduceOp.MIN)
+
+    if rank == 0:
+        # algorithmic bytes: B(k) summed on the device over every
+        # row updated, plus the violated-row scan of every instance and sweep
+        mean_row_bytes = (bytes1 - bytes0) / max(rows_total, 1)
+        alg = (bytes1 - bytes0) + args.steps * args.batch * scan_bytes
+        per_launch_bytes = alg / max(launches, 1)
+        per_launch_s = kernel_ms / 1e3 / max(launches, 1)
+        achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        out = {
+            "metric": "row-updates/sec (itm inner loop)",
+            "value": rows_all / dt_max,
+            "unit": "row-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if float_type else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{inst.name}: scpnrh1-shaped SCP {inst.m}x{inst.n} nnz={inst.nnz}, "
+                            f"inequalities-01, {args.batch} restarts/GPU, {args.cost_kind} costs",
+                "restarts_per_gpu": args.batch,
+                "row_updates": rows_all,
+                "best_objective": None if not np.isfinite(best_t.item()) else float(best_t.item()),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "bxh::sweep_kernel",
+                "launches": int(launches),
+                "avg_launch_ms": kernel_ms / max(launches, 1),
+                "alg_bytes_per_row_update": mean_row_bytes,
+            },
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(inst, params, float_type, args.cpu_seconds,
+                                               args.cpu_threads)
+        elif args.cpu_seconds > 0:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,8 @@ typedef struct bxh_status
     uint32_t rng;         /* minstd_rand0 state after the sweep             */
     uint32_t rows_in_sweep;
     uint64_t row_updates; /* cumulative count of row-loop bodies executed   */
+    double alg_bytes;     /* cumulative algorithmic bytes of those row
+                             updates (bxh_row_bytes summed over them)       */
 } bxh_status;
 
 const char* bxh_last_error(void);
@@ -162,6 +164,11 @@ int bxh_sweep(bxh_handle h, const bxh_sweep_args* args, bxh_status* status_batch
 /* Same without the final synchronisation / copy: for back-to-back launches. */
 int bxh_sweep_async(bxh_handle h, const bxh_sweep_args* args);
 int bxh_status_sync(bxh_handle h, bxh_status* status_batch);
+
+/* Device time of the sweep kernels launched through this handle, measured with
+ * HIP events recorded on the launch stream around every kernel (the H2D copy
+ * of kappa[] is outside the pair).  Synchronises the stream. */
+int bxh_kernel_time(bxh_handle h, double* total_ms, uint64_t* launches, int reset);
 
 /* Algorithmic bytes of one row update of row k:
  * sum_{j in row k} c_j (4 + 2F) + r_k (4 + 5F) + 2F + ceil(r_k / 8) 2,
