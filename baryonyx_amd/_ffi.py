@@ -30,7 +30,7 @@ BXH_ERR_DEVICE = -4
 # every symbol include/bxh.h declares (tests check the library exports them)
 SYMBOLS = [
     "bxh_last_error", "bxh_create", "bxh_destroy", "bxh_set_stream", "bxh_batch",
-    "bxh_nwords", "bxh_rmax", "bxh_set_x", "bxh_get_x", "bxh_set_pi", "bxh_get_pi",
+    "bxh_nwords", "bxh_rmax", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_set_pi", "bxh_get_pi",
     "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset",
     "bxh_order_init", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
     "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time",
@@ -134,6 +134,7 @@ def lib():
             getattr(L, nm).argtypes = [C.c_void_p]
         L.bxh_set_x.argtypes = [C.c_void_p, C.c_int, u64p]
         L.bxh_get_x.argtypes = [C.c_void_p, C.c_int, u64p]
+        L.bxh_set_x_all.argtypes = [C.c_void_p, u64p]
         for nm in ("bxh_set_pi", "bxh_get_pi", "bxh_set_P", "bxh_get_P"):
             getattr(L, nm).argtypes = [C.c_void_p, C.c_int, f64p]
         L.bxh_set_rng.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
@@ -222,6 +223,12 @@ class DeviceBatch:
         assert w.shape[0] == self.nwords
         _check(self.L.bxh_set_x(self.h, i, _p(w, u64p)))
 
+    def set_x_all(self, words):
+        w = np.ascontiguousarray(words, np.uint64)
+        assert w.shape == (self.batch, self.nwords)
+        self._xall = w  # keep alive until the stream has consumed it
+        _check(self.L.bxh_set_x_all(self.h, _p(w, u64p)))
+
     def get_x(self, i):
         w = np.zeros(self.nwords, np.uint64)
         _check(self.L.bxh_get_x(self.h, i, _p(w, u64p)))
@@ -258,7 +265,10 @@ class DeviceBatch:
     def reset(self, i):
         _check(self.L.bxh_reset(self.h, i))
 
-    def order_init(self, order=0):
+    def order_init(self, order=0, sync=True):
+        if not sync:
+            _check(self.L.bxh_order_init(self.h, order, None))
+            return None
         rem = np.zeros(self.batch, np.int32)
         _check(self.L.bxh_order_init(self.h, order, _p(rem, i32p)))
         return rem

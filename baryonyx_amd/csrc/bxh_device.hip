@@ -589,6 +589,21 @@ bxh_get_x(bxh_handle h, int inst, uint64_t* words)
 }
 
 int
+bxh_set_x_all(bxh_handle h, const uint64_t* words)
+{
+    if (!h || !words)
+        return fail(BXH_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    // pageable host memory: the copy is staged before this returns
+    HIP_TRY(hipMemcpyAsync(h->x.p,
+                           words,
+                           static_cast<size_t>(h->batch) * h->nwords * 8,
+                           hipMemcpyHostToDevice,
+                           h->stream));
+    return BXH_OK;
+}
+
+int
 bxh_set_pi(bxh_handle h, int inst, const double* v)
 {
     if (int rc = check_inst(h, inst))
@@ -696,12 +711,13 @@ bxh_order_init(bxh_handle h, int order, int32_t* remaining)
                            h->dp,
                            h->ds);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (remaining)
+    if (remaining) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(hipMemcpy(remaining,
                           h->vcount.p,
                           static_cast<size_t>(h->batch) * sizeof(int),
                           hipMemcpyDeviceToHost));
+    }
     return BXH_OK;
 }
 

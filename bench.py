@@ -6,10 +6,13 @@ instances (BASELINE.json metric), one process per GPU.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A *step* is one sweep (compute_order::run / push_and_run,
-lib/src/itm-common.hpp:682-880) of every solver instance of the rank's batch,
-under the restart driver that mirrors optimize_functor
-(lib/src/itm-optimizer-common.hpp:620-752).  Workload at every N (weak
+A *step* is one restart-sweep of every solver instance of the rank's batch:
+x <- the Bastert start (all rows violated), compute_order::init, one full
+compute_order::run sweep (lib/src/itm-common.hpp:660-680,800-880) with the
+kappa of that restart (best_solution_recorder::reinit's kappa-improve cycle),
+P and pi carried over from the previous restart exactly as optimize_functor
+does (lib/src/itm-optimizer-common.hpp:649-663) -- i.e. m row updates per
+instance and step, the workload BASELINE.md section 2 timed on the CPU.  Workload at every N (weak
 scaling: fixed per-GPU work): BASELINE.json configs[1], an scpnrh1-shaped
 synthetic set-covering instance (1000 x 10000, 5 % density, inequalities-01
 path), 64 restarts per GPU; restarts are sharded over ranks with no data-path
@@ -61,54 +64,62 @@ def make_instance(args):
     )
 
 
-def cpu_baseline(inst, params, float_type, seconds, threads):
-    """Time the oracle's solve loop shape on host cores: every thread runs its
-    own Solver (own seed) from the Bastert start, sweep after sweep with the
-    same kappa schedule, for ~`seconds` of wall time."""
-    from oracle import oracle_ffi as O
-    from baryonyx_amd.driver import compute_delta
+def kappa_cycle(params, k):
+    """kappa of the k-th restart: best_solution_recorder::reinit's
+    kappa-improve branch (itm-optimizer-common.hpp:538-543), wrapping to
+    init_kappa_improve_start when init_kappa_improve_stop is reached."""
+    steps = int(round((params.init_kappa_improve_stop - params.init_kappa_improve_start)
+                      / params.init_kappa_improve_increase))
+    app = params.init_kappa_improve_start + params.init_kappa_improve_increase * (1 + k % max(steps, 1))
+    return params.kappa_min + (params.kappa_max - params.kappa_min) * app
 
-    nthreads = threads if threads > 0 else (os.cpu_count() or 1)
+
+def cpu_run(inst, params, float_type, seconds, nthreads):
+    """The same restart-sweep workload on host threads: every thread owns one
+    oracle Solver (as every reference worker owns one Solver,
+    itm-optimizer-common.hpp:649-653) and repeats {x = Bastert point,
+    compute_order::init, one sweep} for ~`seconds`."""
+    from oracle import oracle_ffi as O
+
     totals = [0] * nthreads
-    sweeps = [0] * nthreads
-    stop_at = time.perf_counter() + seconds
+    stop_at = [0.0]
 
     def work(t):
         s = O.Solver(inst, float_type=float_type, sort_mode=1, cost_norm=4, seed=1000 + t)
         delta = s.compute_delta(params.theta)
-        s.set_x(np.zeros(s.nwords, np.uint64))
-        s.order_init(params.order)
-        kappa, i = params.kappa_min + 0.02 * 0.6, 0
-        while time.perf_counter() < stop_at:
-            r = s.sweep(kappa, delta, params.theta)
-            sweeps[t] += 1
-            if r == 0 or kappa > params.kappa_max or i >= params.limit:
-                # restart like the driver does: keep P / pi, raise kappa start
-                kappa, i = params.kappa_min + 0.04 * 0.6, 0
-                x = s.get_x()
-                x[:] = 0
-                s.set_x(x)
-                s.order_init(params.order)
-                continue
-            if i > params.w:
-                kappa += params.kappa_step * (r / inst.m) ** params.alpha
-            i += 1
+        x0 = np.zeros(s.nwords, np.uint64)
+        k = 0
+        while time.perf_counter() < stop_at[0]:
+            s.set_x(x0)
+            s.order_init(params.order)
+            s.sweep(kappa_cycle(params, k), delta, params.theta)
+            k += 1
         totals[t] = s.row_updates
 
-    t0 = time.perf_counter()
     ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    t0 = time.perf_counter()
+    stop_at[0] = t0 + seconds
     for th in ths:
         th.start()
     for th in ths:
         th.join()
     dt = time.perf_counter() - t0
+    return sum(totals) / dt, sum(totals), dt
+
+
+def cpu_baseline(inst, params, float_type, seconds, threads):
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nthreads = threads if threads > 0 else ncpu
+    one, n1, t1 = cpu_run(inst, params, float_type, seconds * 0.3, 1)
+    allc, na, ta = cpu_run(inst, params, float_type, seconds * 0.7, nthreads)
     return {
-        "value": sum(totals) / dt,
+        "value": allc,
         "unit": "row-updates/s",
         "cores": nthreads,
         "kind": "port",
-        "sample": f"{nthreads} oracle Solver threads x {dt:.1f}s of sweeps on the same "
-                  f"instance from the Bastert start ({sum(sweeps)} sweeps, {sum(totals)} row updates)",
+        "one_thread_value": one,
+        "sample": f"oracle Solver per thread, restart-sweeps of the same instance: "
+                  f"{nthreads} threads x {ta:.1f}s = {na} row updates; 1 thread x {t1:.1f}s = {n1}",
     }
 
 
@@ -129,7 +140,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from baryonyx_amd import _ffi
-    from baryonyx_amd.driver import Params, RestartPool, compute_delta, normalize_costs
+    from baryonyx_amd.driver import Params, compute_delta, normalize_costs
 
     float_type = 1 if args.float_kind == "double" else 0
     F = 8 if float_type else 4
@@ -140,30 +151,38 @@ def main():
 
     dev = _ffi.DeviceBatch(inst, cost, args.batch, float_type=float_type, device=local_rank)
     dev.set_stream(torch.cuda.current_stream().cuda_stream)
-    pool = RestartPool(dev, inst, params, float_type, seed=1 + rank)
-    pool.set_delta(delta)
-    dev.order_init(params.order)
+    for b in range(args.batch):  # one std engine per worker, distinct seeds
+        dev.set_rng(b, 1 + ((1 + rank) * 7919 + b * 104729) % 2147483645)
     scan_bytes = inst.nnz * 4 + inst.nnz / 8  # violated-row scan, per instance and sweep
+    x0 = np.zeros((args.batch, dev.nwords), np.uint64)  # Bastert point of a min-cost SCP
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        pool.step(record_objective=False)
+    def step(k):
+        # one restart of every instance: x <- Bastert point, compute_order::init,
+        # one full sweep (P and pi carry over, as in optimize_functor)
+        dev.set_x_all(x0)
+        dev.order_init(params.order, sync=False)
+        kap = np.full(args.batch, kappa_cycle(params, k))
+        dev.sweep_async(kap, delta, params.theta, order=params.order)
+
+    for k in range(args.warmup):
+        step(k)
     barrier()
     dev.kernel_time(reset=True)
-    bytes0 = float(dev.status()["alg_bytes"].sum())
-    rows_total = 0
+    st0 = dev.status()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rows, st = pool.step(record_objective=False)
-        rows_total += rows
+    for k in range(args.steps):
+        step(args.warmup + k)
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, launches = dev.kernel_time()
-    bytes1 = float(dev.status()["alg_bytes"].sum())
+    st1 = dev.status()
+    rows_total = int(st1["row_updates"].sum() - st0["row_updates"].sum())
+    bytes0, bytes1 = float(st0["alg_bytes"].sum()), float(st1["alg_bytes"].sum())
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     rows_t = torch.tensor([float(rows_total)], dtype=torch.float64, device="cuda")
@@ -176,10 +195,12 @@ def main():
     # incumbent objective after the timed region: min over all restarts, then
     # allreduce(min) over ranks (RCCL over xGMI)
     best = np.inf
-    st = dev.status()
+    from baryonyx_amd.util import x_bits
+    dense = inst.dense_costs()
     for b in range(args.batch):
-        if st["remaining"][b] == 0:
-            best = min(best, pool.objective(b))
+        if st1["remaining"][b] == 0:
+            xb = x_bits(dev.get_x(b), inst.n).astype(np.float64)
+            best = min(best, float((dense * xb).sum() + inst.obj_constant))
     best_t = torch.tensor([best], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(best_t, op=dist.ReduceOp.MIN)

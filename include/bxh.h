@@ -144,6 +144,10 @@ int bxh_rmax(bxh_handle h);
  * worker's random engine. `inst` in [0, batch). */
 int bxh_set_x(bxh_handle h, int inst, const uint64_t* words);
 int bxh_get_x(bxh_handle h, int inst, uint64_t* words);
+/* x of every instance at once, [batch][nwords], stream-ordered (what the
+ * restart loop does between two runs: reinit writes x,
+ * itm-optimizer-common.hpp:660-663) */
+int bxh_set_x_all(bxh_handle h, const uint64_t* words_batch);
 int bxh_set_pi(bxh_handle h, int inst, const double* pi_m);
 int bxh_get_pi(bxh_handle h, int inst, double* pi_m);
 int bxh_set_P(bxh_handle h, int inst, const double* P_nnz);
@@ -154,7 +158,8 @@ int bxh_get_rng(bxh_handle h, int inst, uint32_t* state);
 int bxh_reset(bxh_handle h, int inst);
 
 /* compute_order::init (itm-common.hpp:660-680): rebuild every instance's
- * violated-row list from its current x; remaining[] may be NULL. */
+ * violated-row list from its current x; remaining[] may be NULL, in which
+ * case the call only enqueues the kernel on the stream. */
 int bxh_order_init(bxh_handle h, int order, int32_t* remaining_batch);
 /* the current list (compute_order::R) of one instance */
 int bxh_get_violated(bxh_handle h, int inst, int32_t* rows_m, int32_t* count);
