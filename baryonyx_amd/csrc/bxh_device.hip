@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -72,13 +73,17 @@ struct bxh_handle_s
     int m = 0, n = 0, nnz = 0, rmax = 0, nwords = 0;
     size_t fsize = 8;
     int threads = 256;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0;      // sweep kernel
+    size_t lds_bytes_init = 0; // order_init kernel
+    int version = 1;           // 1: lane-per-column walk, 2: staged column loads
+    int nb = 0;                // v2: 8-element pieces per column and pass
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
 
     // problem
     DevBuf<int> row_ptr, row_col, row_pos, col_ptr, col_row, bmin, bmax, bneg;
+    DevBuf<int2> row_cs;
     DevBuf<signed char> fac_csr, fac_csc;
     DevBuf<unsigned char> cost; // Float[n]
     DevBuf<double> row_bytes;   // [m]
@@ -211,24 +216,32 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
         h->events.emplace_back(e0, e1);
     }
     HIP_TRY(hipEventRecord(h->events[h->events_used].first, h->stream));
-    if (pm1)
-        hipLaunchKernelGGL((bxh::sweep_kernel<Float, true>),
-                           dim3(h->batch),
-                           dim3(h->threads),
-                           h->lds_bytes,
-                           h->stream,
-                           h->dp,
-                           h->ds,
-                           a);
-    else
-        hipLaunchKernelGGL((bxh::sweep_kernel<Float, false>),
-                           dim3(h->batch),
-                           dim3(h->threads),
-                           h->lds_bytes,
-                           h->stream,
-                           h->dp,
-                           h->ds,
-                           a);
+#define BXH_LAUNCH(K)                                                          \
+    hipLaunchKernelGGL(K, dim3(h->batch), dim3(h->threads), h->lds_bytes,      \
+                       h->stream, h->dp, h->ds, a)
+    if (h->version == 2) {
+        if (pm1) {
+            if (h->nb == 8)
+                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 8>));
+            else if (h->nb == 12)
+                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 12>));
+            else
+                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 16>));
+        } else {
+            if (h->nb == 8)
+                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 8>));
+            else if (h->nb == 12)
+                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 12>));
+            else
+                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 16>));
+        }
+    } else {
+        if (pm1)
+            BXH_LAUNCH((bxh::sweep_kernel<Float, true>));
+        else
+            BXH_LAUNCH((bxh::sweep_kernel<Float, false>));
+    }
+#undef BXH_LAUNCH
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->events[h->events_used].second, h->stream));
     ++h->events_used;
@@ -392,15 +405,45 @@ bxh_create(const bxh_problem* pb,
     }
 
     // ---- launch geometry ----------------------------------------------------
+    int cmax = 0;
+    for (int j = 0; j != n; ++j)
+        cmax = std::max(cmax, col_ptr[j + 1] - col_ptr[j]);
+    std::vector<int2> row_cs(static_cast<size_t>(nnz));
+    for (int e = 0; e != nnz; ++e) {
+        const int j = pb->col[e];
+        row_cs[e] = make_int2(col_ptr[j], col_ptr[j + 1] - col_ptr[j]);
+    }
+
+    const int lds_limit = 160 * 1024;
     const bxh::LdsPlan lp =
       bxh::lds_plan(m, h->nwords, rmax, static_cast<int>(h->fsize));
-    if (lp.total > 160 * 1024)
+    if (lp.total > lds_limit)
         return fail(BXH_ERR_UNSUPPORTED,
                     "instance does not fit the one-workgroup-per-instance "
                     "kernel (pi, x and the row buffers must fit 160 KiB of "
                     "LDS)");
+    h->lds_bytes_init = static_cast<size_t>(lp.total);
+    h->version = 1;
     h->lds_bytes = static_cast<size_t>(lp.total);
     h->threads = std::min(1024, std::max(64, bxh::next_pow2(rmax)));
+    const char* force_v1 = std::getenv("BXH_FORCE_V1");
+    if (cmax <= 128 && !(force_v1 && force_v1[0] == '1')) {
+        const int nb = cmax <= 64 ? 8 : (cmax <= 96 ? 12 : 16);
+        // at least as many threads as v1 would use, as many 8-lane groups as fit
+        for (int t = 1024; t >= 128; t >>= 1) {
+            const bxh::LdsPlan2 lp2 = bxh::lds_plan2(
+              m, h->nwords, rmax, static_cast<int>(h->fsize), t / 8, nb);
+            if (lp2.total <= lds_limit) {
+                h->version = 2;
+                h->nb = nb;
+                h->threads = t;
+                h->lds_bytes = static_cast<size_t>(lp2.total);
+                break;
+            }
+            if (t / 8 <= rmax / 4 && t <= 256)
+                break;
+        }
+    }
 
     HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
@@ -409,6 +452,7 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->row_ptr.upload(std::vector<int>(pb->row_ptr, pb->row_ptr + m + 1)));
     HIP_TRY(h->row_col.upload(std::vector<int>(pb->col, pb->col + nnz)));
     HIP_TRY(h->row_pos.upload(row_pos));
+    HIP_TRY(h->row_cs.upload(row_cs));
     HIP_TRY(h->col_ptr.upload(col_ptr));
     HIP_TRY(h->col_row.upload(col_row));
     HIP_TRY(h->bmin.upload(bmin));
@@ -473,17 +517,32 @@ bxh_create(const bxh_problem* pb,
     }
 
     // the kernels may ask for more than the 64 KiB default dynamic LDS
-    if (lp.total > 64 * 1024) {
+    {
+        const int want = static_cast<int>(std::max(h->lds_bytes, h->lds_bytes_init));
 #define BXH_SET_LDS(K)                                                         \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&K),             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                lp.total))
-        BXH_SET_LDS((bxh::sweep_kernel<float, false>));
-        BXH_SET_LDS((bxh::sweep_kernel<float, true>));
-        BXH_SET_LDS((bxh::sweep_kernel<double, false>));
-        BXH_SET_LDS((bxh::sweep_kernel<double, true>));
-        BXH_SET_LDS((bxh::order_init_kernel<float>));
-        BXH_SET_LDS((bxh::order_init_kernel<double>));
+                                want))
+        if (want > 64 * 1024) {
+            BXH_SET_LDS((bxh::sweep_kernel<float, false>));
+            BXH_SET_LDS((bxh::sweep_kernel<float, true>));
+            BXH_SET_LDS((bxh::sweep_kernel<double, false>));
+            BXH_SET_LDS((bxh::sweep_kernel<double, true>));
+            BXH_SET_LDS((bxh::order_init_kernel<float>));
+            BXH_SET_LDS((bxh::order_init_kernel<double>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 12>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 16>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 12>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 16>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 12>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 16>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 12>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 16>));
+        }
 #undef BXH_SET_LDS
     }
 
@@ -492,12 +551,14 @@ bxh_create(const bxh_problem* pb,
     dp.n = n;
     dp.nnz = nnz;
     dp.rmax = rmax;
+    dp.cmax = cmax;
     dp.nwords = h->nwords;
     dp.kind = kind;
     dp.maximize = h->maximize;
     dp.row_ptr = h->row_ptr.p;
     dp.row_col = h->row_col.p;
     dp.row_pos = h->row_pos.p;
+    dp.row_cs = h->row_cs.p;
     dp.col_ptr = h->col_ptr.p;
     dp.col_row = h->col_row.p;
     dp.fac_csr = h->fac_csr.p;
@@ -698,7 +759,7 @@ bxh_order_init(bxh_handle h, int order, int32_t* remaining)
         hipLaunchKernelGGL((bxh::order_init_kernel<float>),
                            dim3(h->batch),
                            dim3(h->threads),
-                           h->lds_bytes,
+                           h->lds_bytes_init,
                            h->stream,
                            h->dp,
                            h->ds);
@@ -706,7 +767,7 @@ bxh_order_init(bxh_handle h, int order, int32_t* remaining)
         hipLaunchKernelGGL((bxh::order_init_kernel<double>),
                            dim3(h->batch),
                            dim3(h->threads),
-                           h->lds_bytes,
+                           h->lds_bytes_init,
                            h->stream,
                            h->dp,
                            h->ds);

@@ -26,11 +26,13 @@ namespace bxh {
 struct DevProblem
 {
     int m, n, nnz, rmax, nwords;
+    int cmax;     // longest column
     int kind;     // bxh_kind
     int maximize; // 0 / 1
     const int* row_ptr;        // [m+1]
     const int* row_col;        // [nnz]   column of CSR element e
     const int* row_pos;        // [nnz]   CSC slot of CSR element e
+    const int2* row_cs;        // [nnz]   {first CSC slot, length} of e's column
     const int* col_ptr;        // [n+1]
     const int* col_row;        // [nnz]   row of CSC slot q
     const signed char* fac_csr; // [nnz]  coefficient of CSR element (101 kinds)
@@ -537,6 +539,367 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
     }
 
     // ---- write back, then compute_violated_constraints ---------------------
+    for (int i = tid; i < pb.m; i += T)
+        pig[i] = pi_s[i];
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        xg[i] = x_s[i];
+    for (int i = tid; i <= pb.rmax; i += T)
+        staleg[i] = stale_s[i];
+
+    const int cnt = rebuild_violated(
+      pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES);
+
+    if (tid == 0) {
+        st.vcount[inst] = cnt;
+        DevStatus s = st.status[inst];
+        s.remaining = cnt;
+        s.pi_changed = misc_s[MS_PICH];
+        s.rng = rng.s;
+        s.rows_in_sweep = (unsigned)nrows;
+        s.row_updates += (unsigned long long)nrows;
+        s.alg_bytes += alg_bytes;
+        st.status[inst] = s;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// v2: staged column loads.
+//
+// The reduced costs of row k need, for each of its r columns, the sequential
+// sums of P and pi over the whole column (about r * c = 25 000 elements for
+// the scpnrh1 shape).  v1 gave each lane one column and a dependent
+// load-add loop: one L2 / Infinity-Cache round trip per element.  Here the
+// row's columns are taken G = blockDim/8 at a time ("pass"); an 8-lane group
+// loads one column in 8-element (64-byte) pieces, all loads of a pass issued
+// back to back (NB pieces per lane in flight), staged through LDS, and then
+// ONE lane per column and per accumulator adds them in CSC order -- the
+// summation order of compute_reduced_costs
+// (itm-solver-inequalities-01.cpp:173-188) is untouched, so results stay
+// bit-identical.  The loads of pass p+1 are in flight while pass p is summed.
+struct LdsPlan2
+{
+    int off_pi, off_x, off_val, off_sp, off_cs, off_pe, off_col, off_stale,
+      off_misc, off_union, stage_i_off, total;
+};
+
+__host__ __device__ inline LdsPlan2
+lds_plan2(int m, int nwords, int rmax, int fsize, int groups, int nb)
+{
+    auto al = [](int v) { return (v + 15) & ~15; };
+    LdsPlan2 p;
+    int o = 0;
+    p.off_pi = o;
+    o = al(o + m * fsize);
+    p.off_x = o;
+    o = al(o + nwords * 8);
+    p.off_val = o;
+    o = al(o + rmax * fsize);
+    p.off_sp = o;
+    o = al(o + rmax * fsize);
+    p.off_cs = o;
+    o = al(o + rmax * 8);
+    p.off_pe = o;
+    o = al(o + rmax * 4);
+    p.off_col = o;
+    o = al(o + rmax * 4);
+    p.off_stale = o;
+    o = al(o + (rmax + 1) * fsize);
+    p.off_misc = o;
+    o = al(o + 96 * 4);
+    p.off_union = o;
+    const int stride = nb * 8 + 1;
+    const int stage = al(groups * stride * fsize) + al(groups * stride * 4);
+    p.stage_i_off = al(groups * stride * fsize);
+    const int n2 = next_pow2(rmax < 2 ? 2 : rmax);
+    const int sortb = al(n2 * 8) + al(n2 * 4);
+    o = al(o + (stage > sortb ? stage : sortb));
+    p.total = o;
+    return p;
+}
+
+template<typename Float, bool PM1, int NB>
+__global__ __launch_bounds__(1024) void
+sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int inst = blockIdx.x;
+    if (a.active && !a.active[inst])
+        return;
+
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int G = T >> 3; // 8-lane groups == columns per pass
+    constexpr int STRIDE = NB * 8 + 1;
+    const LdsPlan2 lp =
+      lds_plan2(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float), G, NB);
+    Float* pi_s = (Float*)(smem + lp.off_pi);
+    unsigned* x_s = (unsigned*)(smem + lp.off_x);
+    Float* val_s = (Float*)(smem + lp.off_val);
+    Float* sp_s = (Float*)(smem + lp.off_sp);
+    int2* cs_s = (int2*)(smem + lp.off_cs);
+    int* pe_s = (int*)(smem + lp.off_pe);
+    int* col_s = (int*)(smem + lp.off_col);
+    Float* stale_s = (Float*)(smem + lp.off_stale);
+    int* misc_s = (int*)(smem + lp.off_misc);
+    Float* d_s = (Float*)(misc_s + MS_D);
+    // union: staging during the reduced-cost passes, sort buffers afterwards
+    Float* stg_p = (Float*)(smem + lp.off_union);
+    int* stg_i = (int*)(smem + lp.off_union + lp.stage_i_off);
+    const int n2max = next_pow2(pb.rmax < 2 ? 2 : pb.rmax);
+    unsigned long long* key_s = (unsigned long long*)(smem + lp.off_union);
+    int* id_s = (int*)(smem + lp.off_union + ((n2max * 8 + 15) & ~15));
+
+    const bool maximize = pb.maximize != 0;
+    const int kind = pb.kind;
+
+    Float* P = (Float*)st.P + (size_t)inst * pb.nnz;
+    Float* pig = (Float*)st.pi + (size_t)inst * pb.m;
+    unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
+    Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
+    int* vlist = st.vlist + (size_t)inst * pb.m;
+    const Float* cost = (const Float*)pb.cost;
+
+    const Float kappa = (Float)a.kappa[inst];
+    const Float delta = (Float)a.delta;
+    const Float theta = (Float)a.theta;
+    const Float obj_amp = (Float)a.obj_amp;
+    const bool push = a.is_push != 0;
+
+    for (int i = tid; i < pb.m; i += T)
+        pi_s[i] = pig[i];
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        x_s[i] = xg[i];
+    for (int i = tid; i <= pb.rmax; i += T)
+        stale_s[i] = staleg[i];
+
+    MinStd rng;
+    rng.s = st.status[inst].rng; // meaningful in thread 0 only
+    const int nrows = st.vcount[inst];
+    double alg_bytes = 0.0; // thread 0 only
+
+    if (tid == 0) {
+        misc_s[MS_PICH] = 0;
+        if (a.order == 2)
+            rng.shuffle(vlist, (unsigned)nrows);
+    }
+    __syncthreads();
+
+    const int g = tid >> 3, l8 = tid & 7;
+
+    for (int it = 0; it < nrows; ++it) {
+        const int k = (a.order == 1) ? vlist[nrows - 1 - it] : vlist[it];
+        const int rs = pb.row_ptr[k];
+        const int r = pb.row_ptr[k + 1] - rs;
+
+        // ---- row descriptor -> LDS ----------------------------------------
+        for (int idx = tid; idx < r; idx += T) {
+            const int e = rs + idx;
+            cs_s[idx] = pb.row_cs[e];
+            pe_s[idx] = pb.row_pos[e];
+            col_s[idx] = pb.row_col[e];
+        }
+        __syncthreads();
+
+        // ---- decrease_preference + compute_reduced_costs, G columns a pass -
+        Float regP[NB];
+        int regI[NB];
+        auto issue = [&](int pass) {
+            const int t = pass * G + g;
+            if (t < r) {
+                const int2 cs = cs_s[t];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int i = b * 8 + l8;
+                    if (i < cs.y) {
+                        regP[b] = P[cs.x + i];
+                        int ri = pb.col_row[cs.x + i];
+                        if (PM1 && pb.fac_csc[cs.x + i] < 0)
+                            ri |= 0x40000000;
+                        regI[b] = ri;
+                    }
+                }
+            }
+        };
+        const int npass = (r + G - 1) / G;
+        issue(0);
+        for (int pass = 0; pass < npass; ++pass) {
+            {
+                const int t = pass * G + g;
+                if (t < r) {
+                    const int c = cs_s[t].y;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const int i = b * 8 + l8;
+                        if (i < c) {
+                            stg_p[g * STRIDE + i] = regP[b];
+                            stg_i[g * STRIDE + i] = regI[b];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (pass + 1 < npass)
+                issue(pass + 1);
+
+            if (tid < G) { // sum_a_p of column t, CSC order
+                const int t = pass * G + tid;
+                if (t < r) {
+                    const int2 cs = cs_s[t];
+                    const int ik = pe_s[t] - cs.x;
+                    const Float* sp = stg_p + tid * STRIDE;
+                    const int* si = stg_i + tid * STRIDE;
+                    Float acc = 0;
+                    for (int i = 0; i < cs.y; ++i) {
+                        Float p = sp[i];
+                        if (i == ik)
+                            p = p * theta; // P[e] *= theta (written by affect)
+                        if (PM1) {
+                            const Float fa = (si[i] & 0x40000000) ? (Float)-1 : (Float)1;
+                            acc += fa * p;
+                        } else {
+                            acc += p;
+                        }
+                    }
+                    sp_s[t] = acc;
+                }
+            } else if (tid < 2 * G) { // sum_a_pi of column t, CSC order
+                const int u = tid - G;
+                const int t = pass * G + u;
+                if (t < r) {
+                    const int c = cs_s[t].y;
+                    const int* si = stg_i + u * STRIDE;
+                    Float acc = 0;
+                    for (int i = 0; i < c; ++i) {
+                        const int ri = si[i];
+                        const Float piv = pi_s[ri & 0x3fffffff];
+                        if (PM1) {
+                            const Float fa = (ri & 0x40000000) ? (Float)-1 : (Float)1;
+                            acc += fa * piv;
+                        } else {
+                            acc += piv;
+                        }
+                    }
+                    val_s[t] = acc;
+                }
+            }
+            __syncthreads();
+        }
+
+        for (int idx = tid; idx < r; idx += T) {
+            const int j = col_s[idx];
+            Float v = cost[j] - val_s[idx] - sp_s[idx];
+            if (PM1 && pb.fac_csr[rs + idx] < 0)
+                v = -v;
+            if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
+                v += obj_amp * (PM1 ? cost[j] : cost[idx]);
+            val_s[idx] = v;
+        }
+        const int n2 = next_pow2(r < 2 ? 2 : r);
+        if (tid == 0)
+            misc_s[MS_TIE] = 0;
+        __syncthreads();
+
+        // ---- calculator_sort: sort, then shuffle every run of equal values -
+        for (int i = tid; i < n2; i += T) {
+            key_s[i] = i < r ? order_key<Float>(val_s[i], maximize) : ~0ull;
+            id_s[i] = i;
+        }
+        __syncthreads();
+        if (r > 1)
+            bitonic_sort(key_s, id_s, n2);
+        for (int i = tid; i + 1 < r; i += T)
+            if (key_s[i] == key_s[i + 1])
+                misc_s[MS_TIE] = 1;
+        __syncthreads();
+
+        // ---- thread 0: tie shuffle, select_variables, pi and d of affect ---
+        if (tid == 0) {
+            alg_bytes += pb.row_bytes[k];
+            if (misc_s[MS_TIE]) {
+                int b0 = 0;
+                for (int i = 1; i <= r; ++i) {
+                    if (i == r || key_s[i] != key_s[b0]) {
+                        rng.shuffle(id_s + b0, (unsigned)(i - b0));
+                        b0 = i;
+                    }
+                }
+            }
+
+            auto Rv = [&](int i) -> Float { // R[i].value, R[r] is stale
+                return i < r ? val_s[id_s[i]] : stale_s[i];
+            };
+            auto stop = [&](Float v) -> bool { // itm-common.hpp:150-163
+                if (v == 0)
+                    return rng.coin();
+                return maximize ? v < 0 : v > 0;
+            };
+
+            const int c_size = PM1 ? pb.bneg[k] : 0;
+            int bkmin = pb.bmin[k], bkmax = pb.bmax[k];
+            int sel;
+            if (kind == 0 || kind == 2 || bkmin == bkmax) {
+                sel = min(bkmin + c_size, r) - 1;
+            } else {
+                if (kind == 1) {
+                    bkmin = min(bkmin, r);
+                    bkmax = min(bkmax, r);
+                } else {
+                    bkmin += c_size;
+                    bkmax = min(bkmax + c_size, r);
+                }
+                sel = bkmax - 1;
+                for (int i = bkmin; i <= bkmax; ++i)
+                    if (stop(Rv(i))) {
+                        sel = i - 1;
+                        break;
+                    }
+            }
+
+            const Float one = 1, two = 2;
+            const Float middle = (two + one) / two;
+            Float d = delta;
+            if (sel < 0) {
+                d += (kappa / (one - kappa)) * (Rv(0) / two);
+            } else if (sel + 1 >= r) {
+                d += (kappa / (one - kappa)) * (Rv(sel) * middle);
+            } else {
+                const Float old_pi = pi_s[k];
+                const Float new_pi = old_pi + ((Rv(sel) + Rv(sel + 1)) / two);
+                pi_s[k] = new_pi;
+                d += (kappa / (one - kappa)) * (Rv(sel + 1) - Rv(sel));
+                if (signbit(old_pi) != signbit(new_pi))
+                    misc_s[MS_PICH] = 1;
+            }
+            misc_s[MS_SEL] = sel;
+            *d_s = d;
+        }
+        __syncthreads();
+
+        // ---- affect: x bits and P of the row, by sorted position -----------
+        {
+            const int sel = misc_s[MS_SEL];
+            const Float d = *d_s;
+            for (int i = tid; i < r; i += T) {
+                const int idx = id_s[i];
+                const int j = col_s[idx];
+                const int pe = pe_s[idx];
+                bool up = i <= sel;
+                if (PM1 && pb.fac_csr[rs + idx] < 0)
+                    up = !up;
+                const Float p = P[pe] * theta;
+                if (up) {
+                    atomicOr(&x_s[j >> 5], 1u << (j & 31));
+                    P[pe] = p + d;
+                } else {
+                    atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
+                    P[pe] = p - d;
+                }
+                stale_s[i] = val_s[idx];
+            }
+        }
+        __syncthreads();
+    }
+
     for (int i = tid; i < pb.m; i += T)
         pig[i] = pi_s[i];
     for (int i = tid; i < 2 * pb.nwords; i += T)

@@ -74,6 +74,26 @@ def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweep
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_sweeps_match_oracle(oracle, bxh, case):
+def test_sweeps_match_oracle(oracle, bxh, case, monkeypatch):
+    """Default kernel choice (staged column loads where the instance fits)."""
+    monkeypatch.delenv("BXH_FORCE_V1", raising=False)
     _, maker, float_type, maximize, order, x0p = case
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
+
+
+@pytest.mark.parametrize("case", CASES[::3], ids=[c[0] for c in CASES[::3]])
+def test_sweeps_match_oracle_lane_per_column_kernel(oracle, bxh, case, monkeypatch):
+    """The lane-per-column kernel stays as the path for instances whose
+    longest column exceeds 128 elements: keep it pinned too."""
+    monkeypatch.setenv("BXH_FORCE_V1", "1")
+    _, maker, float_type, maximize, order, x0p = case
+    run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
+
+
+def test_scpnrh_shaped_rows(oracle, bxh):
+    """Rows of ~500 elements and columns of ~50 (the bench shape, fewer rows):
+    several passes per row, more than one piece per column."""
+    inst = synth.make_scp(120, 10000, 0.05, "int", 31)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=4, push_at=(2,))
+    inst = synth.make_scp(100, 6000, 0.08, "real", 32)
+    run_case(oracle, bxh, inst, 0, False, 0, 0.0, batch=2, sweeps=4, push_at=(3,))
