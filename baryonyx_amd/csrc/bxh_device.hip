@@ -96,6 +96,7 @@ struct bxh_handle_s
     DevBuf<int> vlist, vcount;
     DevBuf<signed char> vflag;
     DevBuf<bxh::DevStatus> status;
+    DevBuf<unsigned long long> prof;
     DevBuf<double> kappa;
     DevBuf<unsigned char> active;
 
@@ -223,6 +224,8 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
         if (pm1) {
             if (h->nb == 8)
                 BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 8>));
+            else if (h->nb == 10)
+                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 10>));
             else if (h->nb == 12)
                 BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 12>));
             else
@@ -230,6 +233,8 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
         } else {
             if (h->nb == 8)
                 BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 8>));
+            else if (h->nb == 10)
+                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 10>));
             else if (h->nb == 12)
                 BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 12>));
             else
@@ -428,7 +433,7 @@ bxh_create(const bxh_problem* pb,
     h->threads = std::min(1024, std::max(64, bxh::next_pow2(rmax)));
     const char* force_v1 = std::getenv("BXH_FORCE_V1");
     if (cmax <= 128 && !(force_v1 && force_v1[0] == '1')) {
-        const int nb = cmax <= 64 ? 8 : (cmax <= 96 ? 12 : 16);
+        const int nb = cmax <= 64 ? 8 : (cmax <= 80 ? 10 : (cmax <= 96 ? 12 : 16));
         // at least as many threads as v1 would use, as many 8-lane groups as fit
         for (int t = 1024; t >= 128; t >>= 1) {
             const bxh::LdsPlan2 lp2 = bxh::lds_plan2(
@@ -488,6 +493,8 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->vcount.alloc(B));
     HIP_TRY(h->vflag.alloc(B * m));
     HIP_TRY(h->status.alloc(B));
+    HIP_TRY(h->prof.alloc(B * 16));
+    HIP_TRY(hipMemset(h->prof.p, 0, B * 16 * sizeof(unsigned long long)));
     HIP_TRY(h->kappa.alloc(B));
     HIP_TRY(h->active.alloc(B));
     HIP_TRY(hipMemset(h->P.p, 0, B * nnz * h->fsize));
@@ -531,15 +538,19 @@ bxh_create(const bxh_problem* pb,
             BXH_SET_LDS((bxh::order_init_kernel<float>));
             BXH_SET_LDS((bxh::order_init_kernel<double>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 10>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 12>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 16>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 10>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 12>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 16>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 10>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 12>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 16>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 10>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 12>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 16>));
         }
@@ -578,6 +589,7 @@ bxh_create(const bxh_problem* pb,
     ds.vcount = h->vcount.p;
     ds.vflag = h->vflag.p;
     ds.status = h->status.p;
+    ds.prof = h->prof.p;
 
     *out = guard.release();
     return BXH_OK;
@@ -892,6 +904,24 @@ bxh_kernel_time(bxh_handle h, double* total_ms, uint64_t* launches, int reset)
         h->kernel_ms = 0.0;
         h->kernel_launches = 0;
     }
+    return BXH_OK;
+}
+
+/* Diagnostic builds only (-DBXH_PROFILE): per-instance phase ticks
+ * (100 MHz wall clock) accumulated by the sweep kernel; zeros otherwise. */
+int
+bxh_debug_profile(bxh_handle h, uint64_t* ticks_batch_x16, int reset)
+{
+    if (!h || !ticks_batch_x16)
+        return fail(BXH_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(ticks_batch_x16,
+                      h->prof.p,
+                      static_cast<size_t>(h->batch) * 16 * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost));
+    if (reset)
+        HIP_TRY(hipMemset(h->prof.p, 0, static_cast<size_t>(h->batch) * 16 * sizeof(unsigned long long)));
     return BXH_OK;
 }
 

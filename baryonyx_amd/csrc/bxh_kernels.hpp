@@ -65,7 +65,23 @@ struct DevState
     int* vcount;         // [batch]
     signed char* vflag;  // [batch][m] scratch
     DevStatus* status;   // [batch]
+    unsigned long long* prof; // [batch][16] phase ticks (profiling build only)
 };
+
+#ifdef BXH_PROFILE
+#define BXH_STAMP(slot)                                                        \
+    do {                                                                       \
+        if (tid == 0) {                                                        \
+            const unsigned long long now_ = wall_clock64();                   \
+            prof_acc[slot] += now_ - prof_t;                                   \
+            prof_t = now_;                                                     \
+        }                                                                      \
+    } while (0)
+#else
+#define BXH_STAMP(slot)                                                        \
+    do {                                                                       \
+    } while (0)
+#endif
 
 struct DevSweep
 {
@@ -194,6 +210,111 @@ bitonic_sort(unsigned long long* key, int* id, int n2)
             __syncthreads();
         }
     }
+}
+
+// Sort of n <= 2 * blockDim (and <= 1024) (key, id) pairs: every wave sorts
+// runs of 64 pairs in registers (bitonic over lane shuffles, no barrier), the
+// runs go to LDS, and each pair finds its final rank as the sum over the other
+// runs of a 6-step binary search (pairs are distinct, so ranks are too).  Two
+// barriers instead of the ~50 of an LDS bitonic sort.  `key_out/id_out`
+// receive the sorted sequence; `key_run/id_run` are scratch of the same size.
+struct KeyId
+{
+    unsigned long long key;
+    int id;
+};
+
+__device__ inline bool
+pair_less(unsigned long long ka, int ia, unsigned long long kb, int ib)
+{
+    return ka < kb || (ka == kb && ia < ib);
+}
+
+template<typename Float>
+__device__ inline void
+run_merge_sort(const Float* val_by_id, // [n] reduced cost of row-local id
+               int n,
+               bool maximize,
+               unsigned long long* key_run,
+               int* id_run,
+               unsigned long long* key_out,
+               int* id_out)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63;
+    const int nruns = (n + 63) >> 6;
+
+    unsigned long long mk[2];
+    int mi[2];
+    int mrun[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int e = tid + s * T; // element index == id before the sort
+        mrun[s] = e >> 6;
+        if (e < n) {
+            mk[s] = order_key<Float>(val_by_id[e], maximize);
+            mi[s] = e;
+        } else {
+            mk[s] = ~0ull;
+            mi[s] = 0x40000000 + e;
+        }
+        if (mrun[s] < nruns) {
+            for (int k = 2; k <= 64; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const unsigned long long ok = __shfl_xor(mk[s], j, 64);
+                    const int oi = __shfl_xor(mi[s], j, 64);
+                    const bool lower = (lane & j) == 0;
+                    const bool asc = (lane & k) == 0;
+                    const bool mine_less = pair_less(mk[s], mi[s], ok, oi);
+                    // keep the smaller one iff (lower == asc)
+                    const bool keep_mine = (lower == asc) ? mine_less : !mine_less;
+                    if (!keep_mine) {
+                        mk[s] = ok;
+                        mi[s] = oi;
+                    }
+                }
+            }
+            key_run[mrun[s] * 64 + lane] = mk[s];
+            id_run[mrun[s] * 64 + lane] = mi[s];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (mrun[s] < nruns && mi[s] < 0x40000000) {
+            int rank = lane;
+            for (int q = 0; q < nruns; ++q) {
+                if (q == mrun[s])
+                    continue;
+                const unsigned long long* kr = key_run + q * 64;
+                const int* ir = id_run + q * 64;
+                int lo = 0; // number of pairs of run q smaller than mine
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int mid = lo + step - 1;
+                    const unsigned long long kq = kr[mid];
+                    bool less = kq < mk[s];
+                    if (kq == mk[s])
+                        less = ir[mid] < mi[s];
+                    if (less)
+                        lo += step;
+                }
+                { // 64th element
+                    const unsigned long long kq = kr[lo < 64 ? lo : 63];
+                    bool less = kq < mk[s];
+                    if (kq == mk[s])
+                        less = ir[lo < 64 ? lo : 63] < mi[s];
+                    if (lo == 63 && less)
+                        lo = 64;
+                }
+                rank += lo;
+            }
+            key_out[rank] = mk[s];
+            id_out[rank] = mi[s];
+        }
+    }
+    __syncthreads();
 }
 
 __device__ inline int
@@ -612,7 +733,7 @@ lds_plan2(int m, int nwords, int rmax, int fsize, int groups, int nb)
     const int stage = al(groups * stride * fsize) + al(groups * stride * 4);
     p.stage_i_off = al(groups * stride * fsize);
     const int n2 = next_pow2(rmax < 2 ? 2 : rmax);
-    const int sortb = al(n2 * 8) + al(n2 * 4);
+    const int sortb = 2 * (al(n2 * 8) + al(n2 * 4)); // runs + merged output
     o = al(o + (stage > sortb ? stage : sortb));
     p.total = o;
     return p;
@@ -648,6 +769,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const int n2max = next_pow2(pb.rmax < 2 ? 2 : pb.rmax);
     unsigned long long* key_s = (unsigned long long*)(smem + lp.off_union);
     int* id_s = (int*)(smem + lp.off_union + ((n2max * 8 + 15) & ~15));
+    const int sort_half = ((n2max * 8 + 15) & ~15) + ((n2max * 4 + 15) & ~15);
+    unsigned long long* key_run = (unsigned long long*)(smem + lp.off_union + sort_half);
+    int* id_run = (int*)(smem + lp.off_union + sort_half + ((n2max * 8 + 15) & ~15));
 
     const bool maximize = pb.maximize != 0;
     const int kind = pb.kind;
@@ -685,6 +809,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     __syncthreads();
 
     const int g = tid >> 3, l8 = tid & 7;
+#ifdef BXH_PROFILE
+    unsigned long long prof_acc[16] = { 0 };
+    unsigned long long prof_t = wall_clock64();
+#endif
 
     for (int it = 0; it < nrows; ++it) {
         const int k = (a.order == 1) ? vlist[nrows - 1 - it] : vlist[it];
@@ -699,6 +827,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             col_s[idx] = pb.row_col[e];
         }
         __syncthreads();
+        BXH_STAMP(0);
 
         // ---- decrease_preference + compute_reduced_costs, G columns a pass -
         Float regP[NB];
@@ -738,10 +867,15 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
             }
             __syncthreads();
+            BXH_STAMP(1);
             if (pass + 1 < npass)
                 issue(pass + 1);
 
-            if (tid < G) { // sum_a_p of column t, CSC order
+            // One lane per column and accumulator walks the staged column in
+            // CSC order; LDS reads are issued 8 at a time so the chain only
+            // pays the add latency (reads past the column's end stay inside
+            // the column's STRIDE slot and are ignored).
+            if (tid < G) { // sum_a_p of column t
                 const int t = pass * G + tid;
                 if (t < r) {
                     const int2 cs = cs_s[t];
@@ -749,40 +883,67 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     const Float* sp = stg_p + tid * STRIDE;
                     const int* si = stg_i + tid * STRIDE;
                     Float acc = 0;
-                    for (int i = 0; i < cs.y; ++i) {
-                        Float p = sp[i];
-                        if (i == ik)
-                            p = p * theta; // P[e] *= theta (written by affect)
-                        if (PM1) {
-                            const Float fa = (si[i] & 0x40000000) ? (Float)-1 : (Float)1;
-                            acc += fa * p;
-                        } else {
-                            acc += p;
+                    for (int i0 = 0; i0 < cs.y; i0 += 8) {
+                        Float buf[8];
+                        int sg[8];
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            buf[b] = sp[i0 + b];
+                            if (PM1)
+                                sg[b] = si[i0 + b];
+                        }
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            if (i0 + b < cs.y) {
+                                Float p = buf[b];
+                                if (i0 + b == ik)
+                                    p = p * theta; // P[e] *= theta (stored by affect)
+                                if (PM1) {
+                                    const Float fa =
+                                      (sg[b] & 0x40000000) ? (Float)-1 : (Float)1;
+                                    acc += fa * p;
+                                } else {
+                                    acc += p;
+                                }
+                            }
                         }
                     }
                     sp_s[t] = acc;
                 }
-            } else if (tid < 2 * G) { // sum_a_pi of column t, CSC order
+            } else if (tid < 2 * G) { // sum_a_pi of column t
                 const int u = tid - G;
                 const int t = pass * G + u;
                 if (t < r) {
                     const int c = cs_s[t].y;
                     const int* si = stg_i + u * STRIDE;
                     Float acc = 0;
-                    for (int i = 0; i < c; ++i) {
-                        const int ri = si[i];
-                        const Float piv = pi_s[ri & 0x3fffffff];
-                        if (PM1) {
-                            const Float fa = (ri & 0x40000000) ? (Float)-1 : (Float)1;
-                            acc += fa * piv;
-                        } else {
-                            acc += piv;
+                    for (int i0 = 0; i0 < c; i0 += 8) {
+                        int ri[8];
+                        Float buf[8];
+#pragma unroll
+                        for (int b = 0; b < 8; ++b)
+                            ri[b] = (i0 + b < c) ? si[i0 + b] : 0;
+#pragma unroll
+                        for (int b = 0; b < 8; ++b)
+                            buf[b] = pi_s[ri[b] & 0x3fffffff];
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            if (i0 + b < c) {
+                                if (PM1) {
+                                    const Float fa =
+                                      (ri[b] & 0x40000000) ? (Float)-1 : (Float)1;
+                                    acc += fa * buf[b];
+                                } else {
+                                    acc += buf[b];
+                                }
+                            }
                         }
                     }
                     val_s[t] = acc;
                 }
             }
             __syncthreads();
+            BXH_STAMP(2);
         }
 
         for (int idx = tid; idx < r; idx += T) {
@@ -798,19 +959,32 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         if (tid == 0)
             misc_s[MS_TIE] = 0;
         __syncthreads();
+        BXH_STAMP(3);
 
         // ---- calculator_sort: sort, then shuffle every run of equal values -
-        for (int i = tid; i < n2; i += T) {
-            key_s[i] = i < r ? order_key<Float>(val_s[i], maximize) : ~0ull;
-            id_s[i] = i;
-        }
-        __syncthreads();
-        if (r > 1)
+        if (r <= 2 * T && r <= 1024) {
+            if (r > 1) {
+                run_merge_sort<Float>(val_s, r, maximize, key_run, id_run, key_s, id_s);
+            } else {
+                if (tid == 0) {
+                    key_s[0] = order_key<Float>(val_s[0], maximize);
+                    id_s[0] = 0;
+                }
+                __syncthreads();
+            }
+        } else {
+            for (int i = tid; i < n2; i += T) {
+                key_s[i] = i < r ? order_key<Float>(val_s[i], maximize) : ~0ull;
+                id_s[i] = i;
+            }
+            __syncthreads();
             bitonic_sort(key_s, id_s, n2);
+        }
         for (int i = tid; i + 1 < r; i += T)
             if (key_s[i] == key_s[i + 1])
                 misc_s[MS_TIE] = 1;
         __syncthreads();
+        BXH_STAMP(4);
 
         // ---- thread 0: tie shuffle, select_variables, pi and d of affect ---
         if (tid == 0) {
@@ -874,6 +1048,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             *d_s = d;
         }
         __syncthreads();
+        BXH_STAMP(5);
 
         // ---- affect: x bits and P of the row, by sorted position -----------
         {
@@ -898,6 +1073,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             }
         }
         __syncthreads();
+        BXH_STAMP(6);
     }
 
     for (int i = tid; i < pb.m; i += T)
@@ -909,6 +1085,12 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 
     const int cnt = rebuild_violated(
       pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES);
+    BXH_STAMP(7);
+#ifdef BXH_PROFILE
+    if (tid == 0)
+        for (int i = 0; i < 16; ++i)
+            st.prof[(size_t)inst * 16 + i] += prof_acc[i];
+#endif
 
     if (tid == 0) {
         st.vcount[inst] = cnt;

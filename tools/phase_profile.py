@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase wall-clock shares of the sweep kernel (needs
+baryonyx_amd/csrc/libbxh_prof.so built with -DBXH_PROFILE). Not a benchmark."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from baryonyx_amd import _ffi, synth  # noqa: E402
+from baryonyx_amd.driver import compute_delta, normalize_costs  # noqa: E402
+
+_ffi.LIB_PATH = os.path.join(_ffi.CSRC, "libbxh_prof.so")
+L = _ffi.lib()
+L.bxh_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+
+float_type = 0 if "--float" in sys.argv else 1
+cost_kind = "real" if "--real" in sys.argv else "int"
+batch = 64
+inst = synth.config_c2(cost_kind)
+cost = normalize_costs(inst.dense_costs(), 4, float_type)
+delta = compute_delta(cost, 0.5, float_type)
+dev = _ffi.DeviceBatch(inst, cost, batch, float_type=float_type)
+x0 = np.zeros((batch, dev.nwords), np.uint64)
+names = ["desc", "stage+wait", "sumS", "combine", "sort", "thread0", "affect", "violated"]
+for step in range(4):
+    dev.set_x_all(x0)
+    dev.order_init(0, sync=False)
+    dev.sweep(0.02 * (step + 1), delta, 0.5)
+    t = np.zeros((batch, 16), np.uint64)
+    L.bxh_debug_profile(dev.h, t.ctypes.data_as(C.POINTER(C.c_uint64)), 1)
+    tot = t.sum(axis=1).mean()
+    ms, n = dev.kernel_time(reset=True)
+    print(f"step {step}: kernel {ms/n:.2f} ms; ticks/instance {tot:.0f} (= {tot/100e3:.2f} ms @100MHz)")
+    for i, nm in enumerate(names):
+        print(f"   {nm:12s} {t[:, i].mean() / tot * 100:6.2f} %   {t[:, i].mean() / 100.0 / 1000:8.3f} us/row")
