@@ -434,10 +434,10 @@ bxh_create(const bxh_problem* pb,
     const char* force_v1 = std::getenv("BXH_FORCE_V1");
     if (cmax <= 128 && !(force_v1 && force_v1[0] == '1')) {
         const int nb = cmax <= 64 ? 8 : (cmax <= 80 ? 10 : (cmax <= 96 ? 12 : 16));
-        // at least as many threads as v1 would use, as many 8-lane groups as fit
-        for (int t = 1024; t >= 128; t >>= 1) {
+        // 16 staging slots per wave; as many waves (up to 8) as LDS allows
+        for (int t = 512; t >= 128; t >>= 1) {
             const bxh::LdsPlan2 lp2 = bxh::lds_plan2(
-              m, h->nwords, rmax, static_cast<int>(h->fsize), t / 8, nb);
+              m, h->nwords, rmax, static_cast<int>(h->fsize), t / 4, nb);
             if (lp2.total <= lds_limit) {
                 h->version = 2;
                 h->nb = nb;
@@ -445,8 +445,6 @@ bxh_create(const bxh_problem* pb,
                 h->lds_bytes = static_cast<size_t>(lp2.total);
                 break;
             }
-            if (t / 8 <= rmax / 4 && t <= 256)
-                break;
         }
     }
 

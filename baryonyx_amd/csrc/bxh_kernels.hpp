@@ -284,31 +284,51 @@ run_merge_sort(const Float* val_by_id, // [n] reduced cost of row-local id
     for (int s = 0; s < 2; ++s) {
         if (mrun[s] < nruns && mi[s] < 0x40000000) {
             int rank = lane;
-            for (int q = 0; q < nruns; ++q) {
-                if (q == mrun[s])
-                    continue;
-                const unsigned long long* kr = key_run + q * 64;
-                const int* ir = id_run + q * 64;
-                int lo = 0; // number of pairs of run q smaller than mine
+            // the searches in the other runs are independent: 8 at a time, so
+            // each of the 7 probe rounds issues 8 LDS reads back to back
+            for (int q0 = 0; q0 < nruns; q0 += 8) {
+                int lo[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    lo[u] = 0;
 #pragma unroll
                 for (int step = 32; step > 0; step >>= 1) {
-                    const int mid = lo + step - 1;
-                    const unsigned long long kq = kr[mid];
-                    bool less = kq < mk[s];
-                    if (kq == mk[s])
-                        less = ir[mid] < mi[s];
-                    if (less)
-                        lo += step;
+                    unsigned long long kq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int q = (q0 + u < nruns) ? q0 + u : q0;
+                        kq[u] = key_run[q * 64 + lo[u] + step - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        bool less = kq[u] < mk[s];
+                        if (kq[u] == mk[s]) {
+                            const int q = (q0 + u < nruns) ? q0 + u : q0;
+                            less = id_run[q * 64 + lo[u] + step - 1] < mi[s];
+                        }
+                        if (less)
+                            lo[u] += step;
+                    }
                 }
-                { // 64th element
-                    const unsigned long long kq = kr[lo < 64 ? lo : 63];
-                    bool less = kq < mk[s];
-                    if (kq == mk[s])
-                        less = ir[lo < 64 ? lo : 63] < mi[s];
-                    if (lo == 63 && less)
-                        lo = 64;
+                {
+                    unsigned long long kq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int q = (q0 + u < nruns) ? q0 + u : q0;
+                        kq[u] = key_run[q * 64 + lo[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int q = (q0 + u < nruns) ? q0 + u : q0;
+                        bool less = kq[u] < mk[s];
+                        if (kq[u] == mk[s])
+                            less = id_run[q * 64 + lo[u]] < mi[s];
+                        if (lo[u] == 63 && less)
+                            lo[u] = 64;
+                        if (q0 + u < nruns && q != mrun[s])
+                            rank += lo[u];
+                    }
                 }
-                rank += lo;
             }
             key_out[rank] = mk[s];
             id_out[rank] = mi[s];
@@ -740,7 +760,7 @@ lds_plan2(int m, int nwords, int rmax, int fsize, int groups, int nb)
 }
 
 template<typename Float, bool PM1, int NB>
-__global__ __launch_bounds__(1024) void
+__global__ __launch_bounds__(512) void
 sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -749,7 +769,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         return;
 
     const int tid = threadIdx.x, T = blockDim.x;
-    const int G = T >> 3; // 8-lane groups == columns per pass
+    const int G = T >> 2; // staging slots: 16 columns for each of the T/64 waves
     constexpr int STRIDE = NB * 8 + 1;
     const LdsPlan2 lp =
       lds_plan2(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float), G, NB);
@@ -808,7 +828,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     }
     __syncthreads();
 
-    const int g = tid >> 3, l8 = tid & 7;
+    const int l8 = tid & 7;
 #ifdef BXH_PROFILE
     unsigned long long prof_acc[16] = { 0 };
     unsigned long long prof_t = wall_clock64();
@@ -829,122 +849,126 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         __syncthreads();
         BXH_STAMP(0);
 
-        // ---- decrease_preference + compute_reduced_costs, G columns a pass -
-        Float regP[NB];
-        int regI[NB];
-        auto issue = [&](int pass) {
-            const int t = pass * G + g;
-            if (t < r) {
-                const int2 cs = cs_s[t];
+        // ---- decrease_preference + compute_reduced_costs ------------------
+        // Wave-private pipeline, no workgroup barrier inside: a wave takes
+        // CW = 16 consecutive columns of the row at a time; 8-lane groups
+        // load them in 64-byte pieces (all loads of a chunk in flight
+        // together, those of the wave's next chunk issued before the sums of
+        // this one), stage them in the wave's LDS slots, then lanes 0-15 add
+        // the P entries and lanes 16-31 the pi entries of one column each,
+        // strictly in CSC order (itm-solver-inequalities-01.cpp:173-188).
+        {
+            constexpr int CW = 16;
+            const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
+            const int g8 = lane >> 3;
+            Float* wst_p = stg_p + wave * (CW * STRIDE);
+            int* wst_i = stg_i + wave * (CW * STRIDE);
+            Float regP[2][NB];
+            int regI[2][NB];
+            auto issue = [&](int chunk) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int i = b * 8 + l8;
-                    if (i < cs.y) {
-                        regP[b] = P[cs.x + i];
-                        int ri = pb.col_row[cs.x + i];
-                        if (PM1 && pb.fac_csc[cs.x + i] < 0)
-                            ri |= 0x40000000;
-                        regI[b] = ri;
-                    }
-                }
-            }
-        };
-        const int npass = (r + G - 1) / G;
-        issue(0);
-        for (int pass = 0; pass < npass; ++pass) {
-            {
-                const int t = pass * G + g;
-                if (t < r) {
-                    const int c = cs_s[t].y;
+                for (int h = 0; h < 2; ++h) {
+                    const int t = chunk * CW + h * 8 + g8;
+                    if (t < r) {
+                        const int2 cs = cs_s[t];
+                        const int pe = pe_s[t];
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const int i = b * 8 + l8;
-                        if (i < c) {
-                            stg_p[g * STRIDE + i] = regP[b];
-                            stg_i[g * STRIDE + i] = regI[b];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            BXH_STAMP(1);
-            if (pass + 1 < npass)
-                issue(pass + 1);
-
-            // One lane per column and accumulator walks the staged column in
-            // CSC order; LDS reads are issued 8 at a time so the chain only
-            // pays the add latency (reads past the column's end stay inside
-            // the column's STRIDE slot and are ignored).
-            if (tid < G) { // sum_a_p of column t
-                const int t = pass * G + tid;
-                if (t < r) {
-                    const int2 cs = cs_s[t];
-                    const int ik = pe_s[t] - cs.x;
-                    const Float* sp = stg_p + tid * STRIDE;
-                    const int* si = stg_i + tid * STRIDE;
-                    Float acc = 0;
-                    for (int i0 = 0; i0 < cs.y; i0 += 8) {
-                        Float buf[8];
-                        int sg[8];
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) {
-                            buf[b] = sp[i0 + b];
-                            if (PM1)
-                                sg[b] = si[i0 + b];
-                        }
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) {
-                            if (i0 + b < cs.y) {
-                                Float p = buf[b];
-                                if (i0 + b == ik)
+                        for (int b = 0; b < NB; ++b) {
+                            const int i = b * 8 + l8;
+                            if (i < cs.y) {
+                                const int q = cs.x + i;
+                                Float p = P[q];
+                                if (q == pe)
                                     p = p * theta; // P[e] *= theta (stored by affect)
-                                if (PM1) {
-                                    const Float fa =
-                                      (sg[b] & 0x40000000) ? (Float)-1 : (Float)1;
-                                    acc += fa * p;
-                                } else {
-                                    acc += p;
-                                }
+                                regP[h][b] = p;
+                                int ri = pb.col_row[q];
+                                if (PM1 && pb.fac_csc[q] < 0)
+                                    ri |= 0x40000000;
+                                regI[h][b] = ri;
                             }
                         }
                     }
-                    sp_s[t] = acc;
                 }
-            } else if (tid < 2 * G) { // sum_a_pi of column t
-                const int u = tid - G;
-                const int t = pass * G + u;
-                if (t < r) {
-                    const int c = cs_s[t].y;
-                    const int* si = stg_i + u * STRIDE;
-                    Float acc = 0;
-                    for (int i0 = 0; i0 < c; i0 += 8) {
-                        int ri[8];
-                        Float buf[8];
+            };
+            const int nchunks = (r + CW - 1) / CW;
+            int chunk = wave;
+            if (chunk < nchunks)
+                issue(chunk);
+            for (; chunk < nchunks; chunk += nwaves) {
 #pragma unroll
-                        for (int b = 0; b < 8; ++b)
-                            ri[b] = (i0 + b < c) ? si[i0 + b] : 0;
+                for (int h = 0; h < 2; ++h) {
+                    const int t = chunk * CW + h * 8 + g8;
+                    if (t < r) {
+                        const int c = cs_s[t].y;
 #pragma unroll
-                        for (int b = 0; b < 8; ++b)
-                            buf[b] = pi_s[ri[b] & 0x3fffffff];
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) {
-                            if (i0 + b < c) {
-                                if (PM1) {
-                                    const Float fa =
-                                      (ri[b] & 0x40000000) ? (Float)-1 : (Float)1;
-                                    acc += fa * buf[b];
-                                } else {
-                                    acc += buf[b];
-                                }
+                        for (int b = 0; b < NB; ++b) {
+                            const int i = b * 8 + l8;
+                            if (i < c) {
+                                wst_p[(h * 8 + g8) * STRIDE + i] = regP[h][b];
+                                wst_i[(h * 8 + g8) * STRIDE + i] = regI[h][b];
                             }
                         }
                     }
-                    val_s[t] = acc;
                 }
+                // LDS operations of one wave execute in order: only the
+                // compiler has to be kept from reordering across this point
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (chunk + nwaves < nchunks)
+                    issue(chunk + nwaves);
+
+                if (lane < 2 * CW) {
+                    const int u = lane & (CW - 1);
+                    const bool is_pi = lane >= CW;
+                    const int t = chunk * CW + u;
+                    if (t < r) {
+                        const int c = cs_s[t].y;
+                        const Float* sp = wst_p + u * STRIDE;
+                        const int* si = wst_i + u * STRIDE;
+                        Float acc = 0;
+                        for (int i0 = 0; i0 < c; i0 += 8) {
+                            Float v[8];
+                            int sg[8];
+                            if (is_pi) {
+#pragma unroll
+                                for (int b = 0; b < 8; ++b)
+                                    sg[b] = (i0 + b < c) ? si[i0 + b] : 0;
+#pragma unroll
+                                for (int b = 0; b < 8; ++b)
+                                    v[b] = pi_s[sg[b] & 0x3fffffff];
+                            } else {
+#pragma unroll
+                                for (int b = 0; b < 8; ++b) {
+                                    v[b] = sp[i0 + b];
+                                    if (PM1)
+                                        sg[b] = si[i0 + b];
+                                }
+                            }
+#pragma unroll
+                            for (int b = 0; b < 8; ++b) {
+                                if (i0 + b < c) {
+                                    if (PM1) {
+                                        const Float fa =
+                                          (sg[b] & 0x40000000) ? (Float)-1 : (Float)1;
+                                        acc += fa * v[b];
+                                    } else {
+                                        acc += v[b];
+                                    }
+                                }
+                            }
+                        }
+                        if (is_pi)
+                            val_s[t] = acc;
+                        else
+                            sp_s[t] = acc;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __syncthreads();
-            BXH_STAMP(2);
         }
+        __syncthreads();
+        BXH_STAMP(2);
 
         for (int idx = tid; idx < r; idx += T) {
             const int j = col_s[idx];
