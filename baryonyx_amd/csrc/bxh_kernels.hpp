@@ -258,22 +258,40 @@ run_merge_sort(const Float* val_by_id, // [n] reduced cost of row-local id
             mk[s] = ~0ull;
             mi[s] = 0x40000000 + e;
         }
-        if (mrun[s] < nruns) {
-            for (int k = 2; k <= 64; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    const unsigned long long ok = __shfl_xor(mk[s], j, 64);
-                    const int oi = __shfl_xor(mi[s], j, 64);
-                    const bool lower = (lane & j) == 0;
-                    const bool asc = (lane & k) == 0;
-                    const bool mine_less = pair_less(mk[s], mi[s], ok, oi);
-                    // keep the smaller one iff (lower == asc)
-                    const bool keep_mine = (lower == asc) ? mine_less : !mine_less;
-                    if (!keep_mine) {
-                        mk[s] = ok;
-                        mi[s] = oi;
-                    }
+    }
+    // mrun[] is wave-uniform; the second slot only exists for n > blockDim
+    const bool two = mrun[1] < nruns;
+    for (int k = 2; k <= 64; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool lower = (lane & j) == 0;
+            const bool asc = (lane & k) == 0;
+            const unsigned long long ok0 = __shfl_xor(mk[0], j, 64);
+            const int oi0 = __shfl_xor(mi[0], j, 64);
+            unsigned long long ok1 = 0;
+            int oi1 = 0;
+            if (two) {
+                ok1 = __shfl_xor(mk[1], j, 64);
+                oi1 = __shfl_xor(mi[1], j, 64);
+            }
+            {
+                const bool mine_less = pair_less(mk[0], mi[0], ok0, oi0);
+                if (!((lower == asc) ? mine_less : !mine_less)) {
+                    mk[0] = ok0;
+                    mi[0] = oi0;
                 }
             }
+            if (two) {
+                const bool mine_less = pair_less(mk[1], mi[1], ok1, oi1);
+                if (!((lower == asc) ? mine_less : !mine_less)) {
+                    mk[1] = ok1;
+                    mi[1] = oi1;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (mrun[s] < nruns) {
             key_run[mrun[s] * 64 + lane] = mk[s];
             id_run[mrun[s] * 64 + lane] = mi[s];
         }
@@ -871,16 +889,13 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     const int t = chunk * CW + h * 8 + g8;
                     if (t < r) {
                         const int2 cs = cs_s[t];
-                        const int pe = pe_s[t];
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
                             const int i = b * 8 + l8;
                             if (i < cs.y) {
                                 const int q = cs.x + i;
-                                Float p = P[q];
-                                if (q == pe)
-                                    p = p * theta; // P[e] *= theta (stored by affect)
-                                regP[h][b] = p;
+                                regP[h][b] = P[q]; // no use of the value here:
+                                                   // all loads stay in flight
                                 int ri = pb.col_row[q];
                                 if (PM1 && pb.fac_csc[q] < 0)
                                     ri |= 0x40000000;
@@ -899,12 +914,16 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 for (int h = 0; h < 2; ++h) {
                     const int t = chunk * CW + h * 8 + g8;
                     if (t < r) {
-                        const int c = cs_s[t].y;
+                        const int2 cs = cs_s[t];
+                        const int ik = pe_s[t] - cs.x; // slot of this row's element
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
                             const int i = b * 8 + l8;
-                            if (i < c) {
-                                wst_p[(h * 8 + g8) * STRIDE + i] = regP[h][b];
+                            if (i < cs.y) {
+                                Float p = regP[h][b];
+                                if (i == ik)
+                                    p = p * theta; // P[e] *= theta (stored by affect)
+                                wst_p[(h * 8 + g8) * STRIDE + i] = p;
                                 wst_i[(h * 8 + g8) * STRIDE + i] = regI[h][b];
                             }
                         }
