@@ -319,13 +319,11 @@ run_merge_sort(const Float* val_by_id, // [n] reduced cost of row-local id
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        bool less = kq[u] < mk[s];
-                        if (kq[u] == mk[s]) {
-                            const int q = (q0 + u < nruns) ? q0 + u : q0;
-                            less = id_run[q * 64 + lo[u] + step - 1] < mi[s];
-                        }
-                        if (less)
-                            lo[u] += step;
+                        const int q = (q0 + u < nruns) ? q0 + u : q0;
+                        const int iq = id_run[q * 64 + lo[u] + step - 1];
+                        const bool less =
+                          kq[u] < mk[s] || (kq[u] == mk[s] && iq < mi[s]);
+                        lo[u] += less ? step : 0;
                     }
                 }
                 {
@@ -338,13 +336,11 @@ run_merge_sort(const Float* val_by_id, // [n] reduced cost of row-local id
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int q = (q0 + u < nruns) ? q0 + u : q0;
-                        bool less = kq[u] < mk[s];
-                        if (kq[u] == mk[s])
-                            less = id_run[q * 64 + lo[u]] < mi[s];
-                        if (lo[u] == 63 && less)
-                            lo[u] = 64;
-                        if (q0 + u < nruns && q != mrun[s])
-                            rank += lo[u];
+                        const int iq = id_run[q * 64 + lo[u]];
+                        const bool less =
+                          kq[u] < mk[s] || (kq[u] == mk[s] && iq < mi[s]);
+                        const int cnt = (lo[u] == 63 && less) ? 64 : lo[u];
+                        rank += (q0 + u < nruns && q != mrun[s]) ? cnt : 0;
                     }
                 }
             }
@@ -891,16 +887,16 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         const int2 cs = cs_s[t];
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
-                            const int i = b * 8 + l8;
-                            if (i < cs.y) {
-                                const int q = cs.x + i;
-                                regP[h][b] = P[q]; // no use of the value here:
-                                                   // all loads stay in flight
-                                int ri = pb.col_row[q];
-                                if (PM1 && pb.fac_csc[q] < 0)
-                                    ri |= 0x40000000;
-                                regI[h][b] = ri;
-                            }
+                            // pieces past the column's end re-read its last
+                            // element (same cache line): no branch per load,
+                            // no use of the values here, all loads in flight
+                            const int i = min(b * 8 + l8, cs.y - 1);
+                            const int q = cs.x + i;
+                            regP[h][b] = P[q];
+                            int ri = pb.col_row[q];
+                            if (PM1)
+                                ri |= (pb.fac_csc[q] < 0) ? 0x40000000 : 0;
+                            regI[h][b] = ri;
                         }
                     }
                 }
@@ -918,14 +914,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         const int ik = pe_s[t] - cs.x; // slot of this row's element
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
-                            const int i = b * 8 + l8;
-                            if (i < cs.y) {
-                                Float p = regP[h][b];
-                                if (i == ik)
-                                    p = p * theta; // P[e] *= theta (stored by affect)
-                                wst_p[(h * 8 + g8) * STRIDE + i] = p;
-                                wst_i[(h * 8 + g8) * STRIDE + i] = regI[h][b];
-                            }
+                            const int i = b * 8 + l8; // < STRIDE: inside the slot
+                            Float p = regP[h][b];
+                            p = (i == ik) ? p * theta : p; // P[e] *= theta
+                            wst_p[(h * 8 + g8) * STRIDE + i] = p;
+                            wst_i[(h * 8 + g8) * STRIDE + i] = regI[h][b];
                         }
                     }
                 }
@@ -945,13 +938,15 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         const Float* sp = wst_p + u * STRIDE;
                         const int* si = wst_i + u * STRIDE;
                         Float acc = 0;
+                        // slots past c hold copies of the column's last
+                        // element (valid row indices): reads need no guard
                         for (int i0 = 0; i0 < c; i0 += 8) {
                             Float v[8];
                             int sg[8];
                             if (is_pi) {
 #pragma unroll
                                 for (int b = 0; b < 8; ++b)
-                                    sg[b] = (i0 + b < c) ? si[i0 + b] : 0;
+                                    sg[b] = si[i0 + b];
 #pragma unroll
                                 for (int b = 0; b < 8; ++b)
                                     v[b] = pi_s[sg[b] & 0x3fffffff];
@@ -965,15 +960,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                             }
 #pragma unroll
                             for (int b = 0; b < 8; ++b) {
-                                if (i0 + b < c) {
-                                    if (PM1) {
-                                        const Float fa =
-                                          (sg[b] & 0x40000000) ? (Float)-1 : (Float)1;
-                                        acc += fa * v[b];
-                                    } else {
-                                        acc += v[b];
-                                    }
-                                }
+                                Float term = v[b];
+                                if (PM1)
+                                    term = (sg[b] & 0x40000000) ? -term : term;
+                                const Float next = acc + term;
+                                acc = (i0 + b < c) ? next : acc;
                             }
                         }
                         if (is_pi)
