@@ -71,20 +71,23 @@ struct bxh_handle_s
     int device = 0;
     int kind = 0, float_type = 1, maximize = 0, batch = 0;
     int m = 0, n = 0, nnz = 0, rmax = 0, nwords = 0;
+    int nnzp = 0; // CSC slots per instance (columns padded to 16 entries)
     size_t fsize = 8;
     int threads = 256;
     size_t lds_bytes = 0;      // sweep kernel
     size_t lds_bytes_init = 0; // order_init kernel
     int version = 1;           // 1: lane-per-column walk, 2: staged column loads
-    int nb = 0;                // v2: 8-element pieces per column and pass
+    int nb = 0;                // v2: 16-entry pieces per staged column
+    int lr = 2;                // v2: 8-column load rounds per wave chunk
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
 
     // problem
-    DevBuf<int> row_ptr, row_col, row_pos, col_ptr, col_row, bmin, bmax, bneg;
+    DevBuf<int> row_ptr, row_col, row_pos, col_start, col_len, col_row, bmin, bmax, bneg;
     DevBuf<int2> row_cs;
-    DevBuf<signed char> fac_csr, fac_csc;
+    DevBuf<signed char> fac_csr;
+    DevBuf<unsigned short> col_row16;
     DevBuf<unsigned char> cost; // Float[n]
     DevBuf<double> row_bytes;   // [m]
     // host copies needed for state import/export and accounting
@@ -221,25 +224,29 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
     hipLaunchKernelGGL(K, dim3(h->batch), dim3(h->threads), h->lds_bytes,      \
                        h->stream, h->dp, h->ds, a)
     if (h->version == 2) {
+#define BXH_V2(PM, NPV)                                                        \
+    do {                                                                       \
+        if (h->lr == 1)                                                        \
+            BXH_LAUNCH((bxh::sweep_kernel_v2<Float, PM, NPV, 1>));             \
+        else                                                                   \
+            BXH_LAUNCH((bxh::sweep_kernel_v2<Float, PM, NPV, 2>));             \
+    } while (0)
         if (pm1) {
-            if (h->nb == 8)
-                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 8>));
-            else if (h->nb == 10)
-                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 10>));
-            else if (h->nb == 12)
-                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 12>));
+            if (h->nb == 4)
+                BXH_V2(true, 4);
+            else if (h->nb == 6)
+                BXH_V2(true, 6);
             else
-                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, true, 16>));
+                BXH_V2(true, 8);
         } else {
-            if (h->nb == 8)
-                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 8>));
-            else if (h->nb == 10)
-                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 10>));
-            else if (h->nb == 12)
-                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 12>));
+            if (h->nb == 4)
+                BXH_V2(false, 4);
+            else if (h->nb == 6)
+                BXH_V2(false, 6);
             else
-                BXH_LAUNCH((bxh::sweep_kernel_v2<Float, false, 16>));
+                BXH_V2(false, 8);
         }
+#undef BXH_V2
     } else {
         if (pm1)
             BXH_LAUNCH((bxh::sweep_kernel<Float, true>));
@@ -344,10 +351,24 @@ bxh_create(const bxh_problem* pb,
         col_ptr[j + 1] += col_ptr[j];
     h->rmax = rmax;
 
-    std::vector<int> col_row(static_cast<size_t>(nnz)), row_pos(static_cast<size_t>(nnz));
-    std::vector<signed char> fac_csr(pm1 ? nnz : 0), fac_csc(pm1 ? nnz : 0);
+    // Device CSC: every column padded to a multiple of 16 entries (128 bytes of
+    // fp64 P), so a column is a whole number of cache-line pieces.  Padding
+    // slots hold row index m (pi_s[m] == 0 on the device) and P == 0 for ever.
+    std::vector<int> col_start(static_cast<size_t>(n)), col_len(static_cast<size_t>(n));
+    long long nnzp_ll = 0;
+    for (int j = 0; j != n; ++j) {
+        col_start[j] = static_cast<int>(nnzp_ll);
+        col_len[j] = col_ptr[j + 1] - col_ptr[j];
+        nnzp_ll += std::max(16, (col_len[j] + 15) & ~15);
+        if (nnzp_ll > 0x7fffffffLL)
+            return fail(BXH_ERR_UNSUPPORTED, "more than 2^31-1 padded elements");
+    }
+    const int nnzp = static_cast<int>(nnzp_ll);
+    h->nnzp = nnzp;
+    std::vector<int> col_row(static_cast<size_t>(nnzp), m), row_pos(static_cast<size_t>(nnz));
+    std::vector<signed char> fac_csr(pm1 ? nnz : 0);
     {
-        std::vector<int> fill(col_ptr.begin(), col_ptr.end() - 1);
+        std::vector<int> fill(col_start);
         for (int k = 0; k != m; ++k)
             for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e) {
                 const int q = fill[pb->col[e]]++;
@@ -355,7 +376,8 @@ bxh_create(const bxh_problem* pb,
                 row_pos[e] = q;
                 if (pm1) {
                     fac_csr[e] = static_cast<signed char>(pb->factor[e]);
-                    fac_csc[q] = static_cast<signed char>(pb->factor[e]);
+                    if (pb->factor[e] < 0)
+                        col_row[q] |= 0x40000000;
                 }
             }
     }
@@ -412,11 +434,11 @@ bxh_create(const bxh_problem* pb,
     // ---- launch geometry ----------------------------------------------------
     int cmax = 0;
     for (int j = 0; j != n; ++j)
-        cmax = std::max(cmax, col_ptr[j + 1] - col_ptr[j]);
+        cmax = std::max(cmax, col_len[j]);
     std::vector<int2> row_cs(static_cast<size_t>(nnz));
     for (int e = 0; e != nnz; ++e) {
         const int j = pb->col[e];
-        row_cs[e] = make_int2(col_ptr[j], col_ptr[j + 1] - col_ptr[j]);
+        row_cs[e] = make_int2(col_start[j], std::max(16, (col_len[j] + 15) & ~15));
     }
 
     const int lds_limit = 160 * 1024;
@@ -432,15 +454,25 @@ bxh_create(const bxh_problem* pb,
     h->lds_bytes = static_cast<size_t>(lp.total);
     h->threads = std::min(1024, std::max(64, bxh::next_pow2(rmax)));
     const char* force_v1 = std::getenv("BXH_FORCE_V1");
-    if (cmax <= 128 && !(force_v1 && force_v1[0] == '1')) {
-        const int nb = cmax <= 64 ? 8 : (cmax <= 80 ? 10 : (cmax <= 96 ? 12 : 16));
-        // 16 staging slots per wave; as many waves (up to 8) as LDS allows
-        for (int t = 512; t >= 128; t >>= 1) {
+    // v2 stages 15-bit row indices: m (the padding index) must fit
+    if (cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1')) {
+        const int np = cmax <= 64 ? 4 : (cmax <= 96 ? 6 : 8);
+        // 8 staging slots per wave with 16 waves (the more waves, the better
+        // the dependent add chains of the column sums overlap), else 16
+        // slots per wave with fewer waves, as LDS allows
+        const char* force_lr = std::getenv("BXH_FORCE_LR");
+        // (the 16-wave variant needs <= 128 VGPRs and spills: measured slower)
+        const int cand[4][2] = { { 512, 2 }, { 256, 2 }, { 128, 2 }, { 1024, 1 } };
+        for (int c = 0; c != 4; ++c) {
+            const int t = cand[c][0], lr = cand[c][1];
+            if (force_lr && force_lr[0] == '2' && lr == 1)
+                continue;
             const bxh::LdsPlan2 lp2 = bxh::lds_plan2(
-              m, h->nwords, rmax, static_cast<int>(h->fsize), t / 4, nb);
+              m, h->nwords, rmax, static_cast<int>(h->fsize), (t / 64) * 8 * lr, np);
             if (lp2.total <= lds_limit) {
                 h->version = 2;
-                h->nb = nb;
+                h->nb = np;
+                h->lr = lr;
                 h->threads = t;
                 h->lds_bytes = static_cast<size_t>(lp2.total);
                 break;
@@ -456,13 +488,20 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->row_col.upload(std::vector<int>(pb->col, pb->col + nnz)));
     HIP_TRY(h->row_pos.upload(row_pos));
     HIP_TRY(h->row_cs.upload(row_cs));
-    HIP_TRY(h->col_ptr.upload(col_ptr));
+    HIP_TRY(h->col_start.upload(col_start));
+    HIP_TRY(h->col_len.upload(col_len));
     HIP_TRY(h->col_row.upload(col_row));
+    if (m < 32768) {
+        std::vector<unsigned short> c16(col_row.size());
+        for (size_t q = 0; q != col_row.size(); ++q)
+            c16[q] = static_cast<unsigned short>((col_row[q] & 0x7fff) |
+                                                 ((col_row[q] & 0x40000000) ? 0x8000 : 0));
+        HIP_TRY(h->col_row16.upload(c16));
+    }
     HIP_TRY(h->bmin.upload(bmin));
     HIP_TRY(h->bmax.upload(bmax));
     HIP_TRY(h->bneg.upload(bneg));
     HIP_TRY(h->fac_csr.upload(fac_csr));
-    HIP_TRY(h->fac_csc.upload(fac_csc));
     {
         std::vector<unsigned char> c;
         if (float_type == BXH_FLOAT)
@@ -483,7 +522,7 @@ bxh_create(const bxh_problem* pb,
     }
 
     const size_t B = static_cast<size_t>(batch);
-    HIP_TRY(h->P.alloc(B * nnz * h->fsize));
+    HIP_TRY(h->P.alloc(B * nnzp * h->fsize));
     HIP_TRY(h->pi.alloc(B * m * h->fsize));
     HIP_TRY(h->rstale.alloc(B * (rmax + 1) * h->fsize));
     HIP_TRY(h->x.alloc(B * 2 * h->nwords));
@@ -495,7 +534,7 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(hipMemset(h->prof.p, 0, B * 16 * sizeof(unsigned long long)));
     HIP_TRY(h->kappa.alloc(B));
     HIP_TRY(h->active.alloc(B));
-    HIP_TRY(hipMemset(h->P.p, 0, B * nnz * h->fsize));
+    HIP_TRY(hipMemset(h->P.p, 0, B * nnzp * h->fsize));
     HIP_TRY(hipMemset(h->pi.p, 0, B * m * h->fsize));
     HIP_TRY(hipMemset(h->rstale.p, 0, B * (rmax + 1) * h->fsize));
     HIP_TRY(hipMemset(h->x.p, 0, B * 2 * h->nwords * sizeof(unsigned)));
@@ -535,22 +574,30 @@ bxh_create(const bxh_problem* pb,
             BXH_SET_LDS((bxh::sweep_kernel<double, true>));
             BXH_SET_LDS((bxh::order_init_kernel<float>));
             BXH_SET_LDS((bxh::order_init_kernel<double>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 10>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 12>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 16>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 10>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 12>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 16>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 10>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 12>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 16>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 10>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 12>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 16>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, 1>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, 2>));
         }
 #undef BXH_SET_LDS
     }
@@ -559,6 +606,7 @@ bxh_create(const bxh_problem* pb,
     dp.m = m;
     dp.n = n;
     dp.nnz = nnz;
+    dp.nnzp = nnzp;
     dp.rmax = rmax;
     dp.cmax = cmax;
     dp.nwords = h->nwords;
@@ -568,10 +616,11 @@ bxh_create(const bxh_problem* pb,
     dp.row_col = h->row_col.p;
     dp.row_pos = h->row_pos.p;
     dp.row_cs = h->row_cs.p;
-    dp.col_ptr = h->col_ptr.p;
+    dp.col_start = h->col_start.p;
+    dp.col_len = h->col_len.p;
     dp.col_row = h->col_row.p;
+    dp.col_row16 = h->col_row16.p;
     dp.fac_csr = h->fac_csr.p;
-    dp.fac_csc = h->fac_csc.p;
     dp.bmin = h->bmin.p;
     dp.bmax = h->bmax.p;
     dp.bneg = h->bneg.p;
@@ -695,11 +744,11 @@ bxh_set_P(bxh_handle h, int inst, const double* v)
 {
     if (int rc = check_inst(h, inst))
         return rc;
-    std::vector<double> csc(static_cast<size_t>(h->nnz));
+    std::vector<double> csc(static_cast<size_t>(h->nnzp), 0.0); // padding stays 0
     for (int e = 0; e != h->nnz; ++e)
         csc[h->h_row_pos[e]] = v[e];
     return set_vec(
-      h, h->P.p + static_cast<size_t>(inst) * h->nnz * h->fsize, csc.data(), h->nnz);
+      h, h->P.p + static_cast<size_t>(inst) * h->nnzp * h->fsize, csc.data(), h->nnzp);
 }
 
 int
@@ -707,11 +756,11 @@ bxh_get_P(bxh_handle h, int inst, double* v)
 {
     if (int rc = check_inst(h, inst))
         return rc;
-    std::vector<double> csc(static_cast<size_t>(h->nnz));
+    std::vector<double> csc(static_cast<size_t>(h->nnzp));
     if (int rc = get_vec(h,
-                         h->P.p + static_cast<size_t>(inst) * h->nnz * h->fsize,
+                         h->P.p + static_cast<size_t>(inst) * h->nnzp * h->fsize,
                          csc.data(),
-                         h->nnz))
+                         h->nnzp))
         return rc;
     for (int e = 0; e != h->nnz; ++e)
         v[e] = csc[h->h_row_pos[e]];
@@ -746,9 +795,9 @@ bxh_reset(bxh_handle h, int inst)
     if (int rc = check_inst(h, inst))
         return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemset(h->P.p + static_cast<size_t>(inst) * h->nnz * h->fsize,
+    HIP_TRY(hipMemset(h->P.p + static_cast<size_t>(inst) * h->nnzp * h->fsize,
                       0,
-                      static_cast<size_t>(h->nnz) * h->fsize));
+                      static_cast<size_t>(h->nnzp) * h->fsize));
     HIP_TRY(hipMemset(h->pi.p + static_cast<size_t>(inst) * h->m * h->fsize,
                       0,
                       static_cast<size_t>(h->m) * h->fsize));

@@ -26,17 +26,22 @@ namespace bxh {
 struct DevProblem
 {
     int m, n, nnz, rmax, nwords;
-    int cmax;     // longest column
+    int nnzp;     // CSC slots per instance: every column padded to 16 entries
+    int cmax;     // longest column (real entries)
     int kind;     // bxh_kind
     int maximize; // 0 / 1
     const int* row_ptr;        // [m+1]
     const int* row_col;        // [nnz]   column of CSR element e
-    const int* row_pos;        // [nnz]   CSC slot of CSR element e
-    const int2* row_cs;        // [nnz]   {first CSC slot, length} of e's column
-    const int* col_ptr;        // [n+1]
-    const int* col_row;        // [nnz]   row of CSC slot q
+    const int* row_pos;        // [nnz]   padded CSC slot of CSR element e
+    const int2* row_cs;        // [nnz]   {first slot, padded length} of e's column
+    const int* col_start;      // [n]     first padded CSC slot of column j
+    const int* col_len;        // [n]     real entries of column j
+    const int* col_row;        // [nnzp]  row of CSC slot q, | 0x40000000 when the
+                               //         coefficient is -1; padding slots hold m
+                               //         (pi_s[m] == 0, P == 0 there for ever)
+    const unsigned short* col_row16; // [nnzp] the same in 16 bits (bit 15 = -1),
+                               //         only when m < 32768 (v2 kernel)
     const signed char* fac_csr; // [nnz]  coefficient of CSR element (101 kinds)
-    const signed char* fac_csc; // [nnz]  coefficient of CSC slot    (101 kinds)
     const int* bmin;           // [m] clamped as the Solver constructor does
     const int* bmax;           // [m]
     const int* bneg;           // [m] negative_factor (== c_size of the row)
@@ -56,7 +61,7 @@ struct DevStatus // == bxh_status
 
 struct DevState
 {
-    void* P;             // [batch][nnz] Float, CSC order
+    void* P;             // [batch][nnzp] Float, padded CSC order
     void* pi;            // [batch][m]   Float
     unsigned* x;         // [batch][2*nwords] u32 halves of the bit_array blocks
     void* rstale;        // [batch][rmax+1] Float: R[].value as the reference's
@@ -68,13 +73,32 @@ struct DevState
     unsigned long long* prof; // [batch][16] phase ticks (profiling build only)
 };
 
+struct Prof
+{
+    unsigned long long acc[16];
+    unsigned long long t;
+};
+#ifdef BXH_PROFILE
+#define BXH_PSTAMP(pp, slot)                                                   \
+    do {                                                                       \
+        if (threadIdx.x == 0) {                                                \
+            const unsigned long long now_ = wall_clock64();                   \
+            (pp)->acc[slot] += now_ - (pp)->t;                                 \
+            (pp)->t = now_;                                                    \
+        }                                                                      \
+    } while (0)
+#else
+#define BXH_PSTAMP(pp, slot)                                                   \
+    do {                                                                       \
+    } while (0)
+#endif
 #ifdef BXH_PROFILE
 #define BXH_STAMP(slot)                                                        \
     do {                                                                       \
         if (tid == 0) {                                                        \
             const unsigned long long now_ = wall_clock64();                   \
-            prof_acc[slot] += now_ - prof_t;                                   \
-            prof_t = now_;                                                     \
+            prof.acc[slot] += now_ - prof.t;                                   \
+            prof.t = now_;                                                     \
         }                                                                      \
     } while (0)
 #else
@@ -238,8 +262,10 @@ run_merge_sort(const Float* val_by_id, // [n] reduced cost of row-local id
                unsigned long long* key_run,
                int* id_run,
                unsigned long long* key_out,
-               int* id_out)
+               int* id_out,
+               Prof* prof)
 {
+    (void)prof;
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63;
     const int nruns = (n + 63) >> 6;
@@ -296,7 +322,9 @@ run_merge_sort(const Float* val_by_id, // [n] reduced cost of row-local id
             id_run[mrun[s] * 64 + lane] = mi[s];
         }
     }
+    BXH_PSTAMP(prof, 8);
     __syncthreads();
+    BXH_PSTAMP(prof, 9);
 
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -348,7 +376,9 @@ run_merge_sort(const Float* val_by_id, // [n] reduced cost of row-local id
             id_out[rank] = mi[s];
         }
     }
+    BXH_PSTAMP(prof, 10);
     __syncthreads();
+    BXH_PSTAMP(prof, 11);
 }
 
 __device__ inline int
@@ -517,7 +547,7 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
     const bool maximize = pb.maximize != 0;
     const int kind = pb.kind;
 
-    Float* P = (Float*)st.P + (size_t)inst * pb.nnz;
+    Float* P = (Float*)st.P + (size_t)inst * pb.nnzp;
     Float* pig = (Float*)st.pi + (size_t)inst * pb.m;
     unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
     Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
@@ -563,14 +593,16 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
             const int pe = pb.row_pos[e];
             Float sum_a_pi = 0;
             Float sum_a_p = 0;
-            const int qe = pb.col_ptr[j + 1];
-            for (int q = pb.col_ptr[j]; q < qe; ++q) {
+            const int q0 = pb.col_start[j];
+            const int qe = q0 + pb.col_len[j];
+            for (int q = q0; q < qe; ++q) {
                 Float p = P[q];
                 if (q == pe)
                     p = p * theta; // P[e] *= theta, written back by affect
-                const Float piv = pi_s[pb.col_row[q]];
+                const int ri = pb.col_row[q];
+                const Float piv = pi_s[ri & 0x3fffffff];
                 if (PM1) {
-                    const Float fa = (Float)pb.fac_csc[q];
+                    const Float fa = (ri & 0x40000000) ? (Float)-1 : (Float)1;
                     sum_a_pi += fa * piv;
                     sum_a_p += fa * p;
                 } else {
@@ -739,13 +771,13 @@ struct LdsPlan2
 };
 
 __host__ __device__ inline LdsPlan2
-lds_plan2(int m, int nwords, int rmax, int fsize, int groups, int nb)
+lds_plan2(int m, int nwords, int rmax, int fsize, int slots, int np)
 {
     auto al = [](int v) { return (v + 15) & ~15; };
     LdsPlan2 p;
     int o = 0;
     p.off_pi = o;
-    o = al(o + m * fsize);
+    o = al(o + (m + 1) * fsize); // + one zero entry read through column padding
     p.off_x = o;
     o = al(o + nwords * 8);
     p.off_val = o;
@@ -763,9 +795,10 @@ lds_plan2(int m, int nwords, int rmax, int fsize, int groups, int nb)
     p.off_misc = o;
     o = al(o + 96 * 4);
     p.off_union = o;
-    const int stride = nb * 8 + 1;
-    const int stage = al(groups * stride * fsize) + al(groups * stride * 4);
-    p.stage_i_off = al(groups * stride * fsize);
+    // staging: per slot np*16 (+2) Float and np*16 (+4) 16-bit row indices
+    const int stage_p = al(slots * (np * 16 + 2) * fsize);
+    const int stage = stage_p + al(slots * (np * 16 + 4) * 2);
+    p.stage_i_off = stage_p;
     const int n2 = next_pow2(rmax < 2 ? 2 : rmax);
     const int sortb = 2 * (al(n2 * 8) + al(n2 * 4)); // runs + merged output
     o = al(o + (stage > sortb ? stage : sortb));
@@ -773,8 +806,8 @@ lds_plan2(int m, int nwords, int rmax, int fsize, int groups, int nb)
     return p;
 }
 
-template<typename Float, bool PM1, int NB>
-__global__ __launch_bounds__(512) void
+template<typename Float, bool PM1, int NP, int LR>
+__global__ __launch_bounds__(LR == 1 ? 1024 : 512) void
 sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -783,10 +816,12 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         return;
 
     const int tid = threadIdx.x, T = blockDim.x;
-    const int G = T >> 2; // staging slots: 16 columns for each of the T/64 waves
-    constexpr int STRIDE = NB * 8 + 1;
+    const int G = (T >> 6) * 8 * LR; // staging slots: 8 * LR columns per wave
+    constexpr int SP = NP * 16 + 2; // Float entries of a P slot (16-byte rows)
+    constexpr int SI = NP * 16 + 4; // 16-bit entries of an index slot (8-byte rows)
+    typedef Float Float2 __attribute__((ext_vector_type(2)));
     const LdsPlan2 lp =
-      lds_plan2(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float), G, NB);
+      lds_plan2(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float), G, NP);
     Float* pi_s = (Float*)(smem + lp.off_pi);
     unsigned* x_s = (unsigned*)(smem + lp.off_x);
     Float* val_s = (Float*)(smem + lp.off_val);
@@ -799,7 +834,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     Float* d_s = (Float*)(misc_s + MS_D);
     // union: staging during the reduced-cost passes, sort buffers afterwards
     Float* stg_p = (Float*)(smem + lp.off_union);
-    int* stg_i = (int*)(smem + lp.off_union + lp.stage_i_off);
+    unsigned short* stg_i = (unsigned short*)(smem + lp.off_union + lp.stage_i_off);
     const int n2max = next_pow2(pb.rmax < 2 ? 2 : pb.rmax);
     unsigned long long* key_s = (unsigned long long*)(smem + lp.off_union);
     int* id_s = (int*)(smem + lp.off_union + ((n2max * 8 + 15) & ~15));
@@ -810,7 +845,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const bool maximize = pb.maximize != 0;
     const int kind = pb.kind;
 
-    Float* P = (Float*)st.P + (size_t)inst * pb.nnz;
+    Float* P = (Float*)st.P + (size_t)inst * pb.nnzp;
     Float* pig = (Float*)st.pi + (size_t)inst * pb.m;
     unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
     Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
@@ -825,6 +860,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 
     for (int i = tid; i < pb.m; i += T)
         pi_s[i] = pig[i];
+    if (tid == 0)
+        pi_s[pb.m] = 0; // read through the padding of the staged columns
     for (int i = tid; i < 2 * pb.nwords; i += T)
         x_s[i] = xg[i];
     for (int i = tid; i <= pb.rmax; i += T)
@@ -843,9 +880,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     __syncthreads();
 
     const int l8 = tid & 7;
+    Prof prof;
 #ifdef BXH_PROFILE
-    unsigned long long prof_acc[16] = { 0 };
-    unsigned long long prof_t = wall_clock64();
+    for (int i = 0; i < 16; ++i)
+        prof.acc[i] = 0;
+    prof.t = wall_clock64();
 #endif
 
     for (int it = 0; it < nrows; ++it) {
@@ -864,39 +903,46 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         BXH_STAMP(0);
 
         // ---- decrease_preference + compute_reduced_costs ------------------
-        // Wave-private pipeline, no workgroup barrier inside: a wave takes
-        // CW = 16 consecutive columns of the row at a time; 8-lane groups
-        // load them in 64-byte pieces (all loads of a chunk in flight
-        // together, those of the wave's next chunk issued before the sums of
-        // this one), stage them in the wave's LDS slots, then lanes 0-15 add
-        // the P entries and lanes 16-31 the pi entries of one column each,
-        // strictly in CSC order (itm-solver-inequalities-01.cpp:173-188).
+        // Wave-private pipeline, no workgroup barrier inside.  Columns are
+        // stored padded to 16 entries (128 bytes of P), so a column is a
+        // whole number of 16-entry pieces: an 8-lane group loads one piece
+        // per instruction (16 B of P + 8 B of row indices per lane = exactly
+        // one cache line of P), all pieces of a 16-column chunk in flight
+        // together and those of the wave's next chunk issued before the sums
+        // of this one.  The pieces are staged in the wave's LDS slots; lanes
+        // 0-15 then add the P entries and lanes 16-31 the pi entries of one
+        // column each, strictly in CSC order
+        // (itm-solver-inequalities-01.cpp:173-188); padding entries are +0.0
+        // / pi_s[m] == +0.0 and leave the sums bit-identical.
         {
-            constexpr int CW = 16;
+            constexpr int CW = 8 * LR; // columns of a wave's chunk
             const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
             const int g8 = lane >> 3;
-            Float* wst_p = stg_p + wave * (CW * STRIDE);
-            int* wst_i = stg_i + wave * (CW * STRIDE);
-            Float regP[2][NB];
-            int regI[2][NB];
+            Float* wst_p = stg_p + wave * (CW * SP);
+            unsigned short* wst_i = stg_i + wave * (CW * SI);
+            Float2 regP[LR][NP];
+            unsigned regI[LR][NP]; // two 16-bit row indices per lane and piece
+            const char* Pb = reinterpret_cast<const char*>(P);
+            const char* Ib = reinterpret_cast<const char*>(pb.col_row16);
             auto issue = [&](int chunk) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < LR; ++h) {
                     const int t = chunk * CW + h * 8 + g8;
                     if (t < r) {
                         const int2 cs = cs_s[t];
+                        const unsigned last = (unsigned)(cs.y >> 4) - 1u;
+                        const unsigned q0 = (unsigned)cs.x + 2u * (unsigned)l8;
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) {
+                        for (int b = 0; b < NP; ++b) {
                             // pieces past the column's end re-read its last
-                            // element (same cache line): no branch per load,
-                            // no use of the values here, all loads in flight
-                            const int i = min(b * 8 + l8, cs.y - 1);
-                            const int q = cs.x + i;
-                            regP[h][b] = P[q];
-                            int ri = pb.col_row[q];
-                            if (PM1)
-                                ri |= (pb.fac_csc[q] < 0) ? 0x40000000 : 0;
-                            regI[h][b] = ri;
+                            // piece (a cache hit): no branch per load and no
+                            // use of the values here, so all stay in flight;
+                            // 32-bit offsets from a uniform base
+                            const unsigned q = q0 + (min((unsigned)b, last) << 4);
+                            regP[h][b] = *reinterpret_cast<const Float2*>(
+                              Pb + q * (unsigned)sizeof(Float));
+                            regI[h][b] =
+                              *reinterpret_cast<const unsigned*>(Ib + q * 2u);
                         }
                     }
                 }
@@ -907,18 +953,17 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 issue(chunk);
             for (; chunk < nchunks; chunk += nwaves) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < LR; ++h) {
                     const int t = chunk * CW + h * 8 + g8;
                     if (t < r) {
-                        const int2 cs = cs_s[t];
-                        const int ik = pe_s[t] - cs.x; // slot of this row's element
+                        // every piece is stored; the adders only read the
+                        // column's own (padded) length
+                        Float* dp = wst_p + (h * 8 + g8) * SP + 2 * l8;
+                        unsigned short* di = wst_i + (h * 8 + g8) * SI + 2 * l8;
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            const int i = b * 8 + l8; // < STRIDE: inside the slot
-                            Float p = regP[h][b];
-                            p = (i == ik) ? p * theta : p; // P[e] *= theta
-                            wst_p[(h * 8 + g8) * STRIDE + i] = p;
-                            wst_i[(h * 8 + g8) * STRIDE + i] = regI[h][b];
+                        for (int b = 0; b < NP; ++b) {
+                            *reinterpret_cast<Float2*>(dp + b * 16) = regP[h][b];
+                            *reinterpret_cast<unsigned*>(di + b * 16) = regI[h][b];
                         }
                     }
                 }
@@ -926,45 +971,61 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 // compiler has to be kept from reordering across this point
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                BXH_STAMP(12);
                 if (chunk + nwaves < nchunks)
                     issue(chunk + nwaves);
+                BXH_STAMP(13);
 
                 if (lane < 2 * CW) {
                     const int u = lane & (CW - 1);
                     const bool is_pi = lane >= CW;
                     const int t = chunk * CW + u;
                     if (t < r) {
-                        const int c = cs_s[t].y;
-                        const Float* sp = wst_p + u * STRIDE;
-                        const int* si = wst_i + u * STRIDE;
+                        const int2 cs = cs_s[t];
+                        const int cpad = cs.y;
+                        if (!is_pi) { // P[e] *= theta for this row's entry
+                            Float* pk = wst_p + u * SP + (pe_s[t] - cs.x);
+                            *pk = *pk * theta; // (stored to HBM by affect)
+                        }
+                        const Float2* sp2 =
+                          reinterpret_cast<const Float2*>(wst_p + u * SP);
+                        const uint2* si2 =
+                          reinterpret_cast<const uint2*>(wst_i + u * SI);
                         Float acc = 0;
-                        // slots past c hold copies of the column's last
-                        // element (valid row indices): reads need no guard
-                        for (int i0 = 0; i0 < c; i0 += 8) {
-                            Float v[8];
-                            int sg[8];
+                        for (int i0 = 0; i0 < cpad; i0 += 16) {
+                            Float v[16];
+                            unsigned sg[8]; // 16 packed 16-bit indices
+                            if (is_pi || PM1) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const uint2 w = si2[(i0 >> 2) + b];
+                                    sg[2 * b] = w.x;
+                                    sg[2 * b + 1] = w.y;
+                                }
+                            }
                             if (is_pi) {
 #pragma unroll
-                                for (int b = 0; b < 8; ++b)
-                                    sg[b] = si[i0 + b];
-#pragma unroll
-                                for (int b = 0; b < 8; ++b)
-                                    v[b] = pi_s[sg[b] & 0x3fffffff];
+                                for (int b = 0; b < 8; ++b) {
+                                    v[2 * b] = pi_s[sg[b] & 0x7fff];
+                                    v[2 * b + 1] = pi_s[(sg[b] >> 16) & 0x7fff];
+                                }
                             } else {
 #pragma unroll
                                 for (int b = 0; b < 8; ++b) {
-                                    v[b] = sp[i0 + b];
-                                    if (PM1)
-                                        sg[b] = si[i0 + b];
+                                    const Float2 w = sp2[(i0 >> 1) + b];
+                                    v[2 * b] = w.x;
+                                    v[2 * b + 1] = w.y;
                                 }
                             }
 #pragma unroll
-                            for (int b = 0; b < 8; ++b) {
+                            for (int b = 0; b < 16; ++b) {
                                 Float term = v[b];
-                                if (PM1)
-                                    term = (sg[b] & 0x40000000) ? -term : term;
-                                const Float next = acc + term;
-                                acc = (i0 + b < c) ? next : acc;
+                                if (PM1) {
+                                    const unsigned neg =
+                                      (sg[b >> 1] >> ((b & 1) ? 31 : 15)) & 1u;
+                                    term = neg ? -term : term;
+                                }
+                                acc += term;
                             }
                         }
                         if (is_pi)
@@ -975,8 +1036,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                BXH_STAMP(14);
             }
         }
+        BXH_STAMP(15);
         __syncthreads();
         BXH_STAMP(2);
 
@@ -998,7 +1061,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // ---- calculator_sort: sort, then shuffle every run of equal values -
         if (r <= 2 * T && r <= 1024) {
             if (r > 1) {
-                run_merge_sort<Float>(val_s, r, maximize, key_run, id_run, key_s, id_s);
+                BXH_STAMP(4);
+                run_merge_sort<Float>(val_s, r, maximize, key_run, id_run, key_s, id_s, &prof);
             } else {
                 if (tid == 0) {
                     key_s[0] = order_key<Float>(val_s[0], maximize);
@@ -1123,7 +1187,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 #ifdef BXH_PROFILE
     if (tid == 0)
         for (int i = 0; i < 16; ++i)
-            st.prof[(size_t)inst * 16 + i] += prof_acc[i];
+            st.prof[(size_t)inst * 16 + i] += prof.acc[i];
 #endif
 
     if (tid == 0) {

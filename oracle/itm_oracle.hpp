@@ -486,6 +486,7 @@ struct Solver
     std::unique_ptr<ZSubSolvers<Float>> zsub;
 
     std::uint64_t row_updates = 0; // metric counter
+    std::uint64_t tie_rows = 0;    // rows whose sort met equal reduced costs
 
     Solver(random_engine& rng_,
            const Constraints& cs_,
@@ -583,14 +584,18 @@ struct Solver
                 });
         }
 
+        bool tie = false;
         auto ret = begin++;
         for (; begin != end; ++begin) {
             if (ret->value != begin->value) {
+                tie = tie || (begin - ret) > 1;
                 std::shuffle(ret, begin, rng);
                 ret = begin;
             }
         }
+        tie = tie || (begin - ret) > 1;
         std::shuffle(ret, begin, rng);
+        tie_rows += tie ? 1 : 0;
     }
 
     // decrease_preference (all solvers, e.g. inequalities-01.cpp:158-164)

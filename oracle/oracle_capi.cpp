@@ -90,6 +90,7 @@ struct HandleBase
     virtual std::uint32_t get_rng() = 0;
     virtual void set_rng(std::uint32_t s) = 0;
     virtual std::uint64_t row_updates() = 0;
+    virtual std::uint64_t tie_rows() = 0;
     virtual double objective() = 0;
     virtual void order_init(int order) = 0;
     virtual int violated(std::int32_t* out) = 0;
@@ -209,6 +210,7 @@ struct Handle : HandleBase
         is >> rng;
     }
     std::uint64_t row_updates() override { return slv->row_updates; }
+    std::uint64_t tie_rows() override { return slv->tie_rows; }
     double objective() override { return original.results(x, obj.constant); }
     void order_init(int order) override
     {
@@ -419,6 +421,11 @@ uint64_t
 orc_solver_row_updates(void* h)
 {
     return H(h)->row_updates();
+}
+uint64_t
+orc_solver_tie_rows(void* h)
+{
+    return H(h)->tie_rows();
 }
 double
 orc_solver_objective(void* h)

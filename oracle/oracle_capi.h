@@ -90,6 +90,7 @@ void orc_solver_set_P(void* h, const double* in_nnz);
 uint32_t orc_solver_get_rng(void* h);
 void orc_solver_set_rng(void* h, uint32_t state);
 uint64_t orc_solver_row_updates(void* h);
+uint64_t orc_solver_tie_rows(void* h); /* rows that met equal reduced costs */
 double orc_solver_objective(void* h); /* Cost::results(x, constant) */
 
 /* compute_order::init / run / push_and_run */

@@ -119,6 +119,8 @@ def lib():
         L.orc_solver_set_rng.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_solver_row_updates.argtypes = [C.c_void_p]
         L.orc_solver_row_updates.restype = C.c_uint64
+        L.orc_solver_tie_rows.argtypes = [C.c_void_p]
+        L.orc_solver_tie_rows.restype = C.c_uint64
         L.orc_solver_objective.argtypes = [C.c_void_p]
         L.orc_solver_objective.restype = C.c_double
         L.orc_solver_order_init.argtypes = [C.c_void_p, C.c_int]
@@ -268,6 +270,10 @@ class Solver:
     @property
     def row_updates(self):
         return self.L.orc_solver_row_updates(self.h)
+
+    @property
+    def tie_rows(self):
+        return self.L.orc_solver_tie_rows(self.h)
 
     def objective(self):
         return self.L.orc_solver_objective(self.h)
