@@ -208,6 +208,57 @@ order_key(Float v, bool maximize)
     return maximize ? ~b : b;
 }
 
+// Inverse of order_key (the value's sign of zero is lost: +0.0 comes back,
+// which no arithmetic of affect() can tell from -0.0 when the row has no
+// equal reduced costs).
+template<typename Float>
+__device__ inline Float
+key_value(unsigned long long k, bool maximize)
+{
+    if (maximize)
+        k = ~k;
+    k = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return (Float)__longlong_as_double((long long)k);
+}
+
+__device__ inline unsigned long long
+wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+__device__ inline unsigned long long
+wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// Open-addressing insert of a non-zero key; returns true when the key was
+// already there (two equal reduced costs in the row).
+__device__ inline bool
+hash_insert(unsigned long long* tab, unsigned mask, unsigned long long key)
+{
+    unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&tab[h], 0ull, key);
+        if (old == 0ull)
+            return false;
+        if (old == key)
+            return true;
+        h = (h + 1) & mask;
+    }
+}
+
 // In-place bitonic sort of (key, id) pairs in LDS; n2 is a power of two.
 // All pairs are distinct (ids are), so the result is the unique sorted order:
 // "by value, ties by row-local id" -- the canonical tie rule of DESIGN.md.
@@ -488,8 +539,11 @@ enum
     MS_TIE = 1,
     MS_PICH = 2,
     MS_CNT = 3,
+    MS_FAST = 4,   // 1: the row was resolved without sorting
+    MS_SELMODE = 5, // 0: none up, 1: all up, 2: up iff key <= threshold
     MS_D = 8,      // Float d (8 bytes reserved)
-    MS_WAVES = 16  // 64 ints of scratch
+    MS_THR = 10,   // u64 threshold key (8 bytes)
+    MS_WAVES = 16  // 64 ints of scratch (also the per-wave partials below)
 };
 
 template<typename Float>
@@ -767,7 +821,7 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
 struct LdsPlan2
 {
     int off_pi, off_x, off_val, off_sp, off_cs, off_pe, off_col, off_stale,
-      off_misc, off_union, stage_i_off, total;
+      off_misc, off_part, off_union, stage_i_off, total;
 };
 
 __host__ __device__ inline LdsPlan2
@@ -794,6 +848,8 @@ lds_plan2(int m, int nwords, int rmax, int fsize, int slots, int np)
     o = al(o + (rmax + 1) * fsize);
     p.off_misc = o;
     o = al(o + 96 * 4);
+    p.off_part = o; // per-wave partial reductions of the sort-free selection
+    o = al(o + 16 * 8 * 8);
     p.off_union = o;
     // staging: per slot np*16 (+2) Float and np*16 (+4) 16-bit row indices
     const int stage_p = al(slots * (np * 16 + 2) * fsize);
@@ -838,6 +894,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const int n2max = next_pow2(pb.rmax < 2 ? 2 : pb.rmax);
     unsigned long long* key_s = (unsigned long long*)(smem + lp.off_union);
     int* id_s = (int*)(smem + lp.off_union + ((n2max * 8 + 15) & ~15));
+    // tie-detection table of the sort-free path: 2 * n2max 64-bit slots, over
+    // the same bytes (the two paths never run for the same row)
+    unsigned long long* htab = (unsigned long long*)(smem + lp.off_union);
+    unsigned long long* part_s = (unsigned long long*)(smem + lp.off_part);
     const int sort_half = ((n2max * 8 + 15) & ~15) + ((n2max * 4 + 15) & ~15);
     unsigned long long* key_run = (unsigned long long*)(smem + lp.off_union + sort_half);
     int* id_run = (int*)(smem + lp.off_union + sort_half + ((n2max * 8 + 15) & ~15));
@@ -1053,10 +1113,252 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             val_s[idx] = v;
         }
         const int n2 = next_pow2(r < 2 ? 2 : r);
-        if (tid == 0)
+        if (tid == 0) {
             misc_s[MS_TIE] = 0;
+            misc_s[MS_FAST] = 0;
+        }
+        // the tie-detection table shares LDS with the staging slots: clear
+        const unsigned hmask = (unsigned)(2 * n2max - 1);
+        for (int i = tid; i < 2 * n2max; i += T)
+            htab[i] = 0ull;
         __syncthreads();
         BXH_STAMP(3);
+
+        // ---- selection without sorting (rows with no two equal reduced
+        // costs whose select_variables / affect only need the extreme order
+        // statistics: the set-covering / set-partitioning shapes) ------------
+        // Sorted by calculator_sort a row reads  N.. N Z S.. S  where N never
+        // stops the scan of select_variables, Z (== 0) flips a coin and S
+        // stops it (itm-common.hpp:150-163).  The scan result, R[selected],
+        // R[selected + 1] and "is this entry at or before selected" then follow
+        // from the class counts, the two smallest / the largest key and the
+        // keys next to the class borders.  Anything else (a tie, which needs
+        // the shuffle and its RNG draws, or an interior rank) takes the sort.
+        bool fast = false;
+        unsigned long long mykey[2] = { 0ull, 0ull };
+        if (r <= 2 * T && r >= 2) {
+            const unsigned long long K0 = order_key<Float>((Float)0, maximize);
+            unsigned long long mn1 = ~0ull, mn2 = ~0ull, mx1 = 0ull, mxN = 0ull, mnS = ~0ull;
+            int cN = 0, cZ = 0;
+            bool tie = false;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int e = tid + s2 * T;
+                const bool have = e < r;
+                unsigned long long k = 0ull;
+                if (have) {
+                    k = order_key<Float>(val_s[e], maximize);
+                    tie = hash_insert(htab, hmask, k) || tie;
+                }
+                mykey[s2] = k;
+                const bool isN = have && k < K0, isZ = have && k == K0;
+                const bool isS = have && k > K0;
+                cN += __popcll(__ballot(isN));
+                cZ += __popcll(__ballot(isZ));
+                if (have) {
+                    if (k < mn1) {
+                        mn2 = mn1;
+                        mn1 = k;
+                    } else if (k < mn2) {
+                        mn2 = k;
+                    }
+                    mx1 = k > mx1 ? k : mx1;
+                }
+                if (isN)
+                    mxN = k > mxN ? k : mxN;
+                if (isS)
+                    mnS = k < mnS ? k : mnS;
+            }
+            // wave reductions (two smallest: merge of sorted pairs)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long b1 = __shfl_xor(mn1, o, 64);
+                const unsigned long long b2 = __shfl_xor(mn2, o, 64);
+                const unsigned long long lo1 = b1 < mn1 ? b1 : mn1;
+                const unsigned long long hi1 = b1 < mn1 ? mn1 : b1;
+                const unsigned long long lo2 = b2 < mn2 ? b2 : mn2;
+                mn1 = lo1;
+                mn2 = hi1 < lo2 ? hi1 : lo2;
+            }
+            mx1 = wave_max_u64(mx1);
+            mxN = wave_max_u64(mxN);
+            mnS = wave_min_u64(mnS);
+            const bool wtie = __ballot(tie) != 0ull;
+            {
+                const int wave = tid >> 6, lane = tid & 63;
+                unsigned long long* part = part_s + wave * 8;
+                if (lane == 0) {
+                    part[0] = mn1;
+                    part[1] = mn2;
+                    part[2] = mx1;
+                    part[3] = mxN;
+                    part[4] = mnS;
+                    part[5] = ((unsigned long long)(unsigned)cN << 32) | (unsigned)cZ;
+                    part[6] = wtie ? 1ull : 0ull;
+                }
+            }
+            BXH_STAMP(8);
+            __syncthreads();
+            BXH_STAMP(9);
+            if (tid == 0) {
+                const int nw = T >> 6;
+                const unsigned long long* part = part_s;
+                unsigned long long g1 = ~0ull, g2 = ~0ull, gx = 0ull, gxN = 0ull, gnS = ~0ull;
+                int nN = 0, nZ = 0;
+                bool anytie = false;
+                for (int w = 0; w < nw; ++w) {
+                    const unsigned long long a1 = part[w * 8], a2 = part[w * 8 + 1];
+                    const unsigned long long lo1 = a1 < g1 ? a1 : g1;
+                    const unsigned long long hi1 = a1 < g1 ? g1 : a1;
+                    const unsigned long long lo2 = a2 < g2 ? a2 : g2;
+                    g1 = lo1;
+                    g2 = hi1 < lo2 ? hi1 : lo2;
+                    gx = part[w * 8 + 2] > gx ? part[w * 8 + 2] : gx;
+                    gxN = part[w * 8 + 3] > gxN ? part[w * 8 + 3] : gxN;
+                    gnS = part[w * 8 + 4] < gnS ? part[w * 8 + 4] : gnS;
+                    nN += (int)(part[w * 8 + 5] >> 32);
+                    nZ += (int)(part[w * 8 + 5] & 0xffffffffu);
+                    anytie = anytie || part[w * 8 + 6] != 0ull;
+                }
+                bool ok = !anytie;
+                const unsigned saved_rng = rng.s;
+                int sel = 0;
+                unsigned long long k_sel = 0ull, k_sel1 = 0ull;
+                if (ok) {
+                    auto stop = [&](Float v) -> bool { // itm-common.hpp:150-163
+                        if (v == 0)
+                            return rng.coin();
+                        return maximize ? v < 0 : v > 0;
+                    };
+                    const int c_size = PM1 ? pb.bneg[k] : 0;
+                    int bkmin = pb.bmin[k], bkmax = pb.bmax[k];
+                    if (kind == 0 || kind == 2 || bkmin == bkmax) {
+                        sel = min(bkmin + c_size, r) - 1;
+                    } else {
+                        if (kind == 1) {
+                            bkmin = min(bkmin, r);
+                            bkmax = min(bkmax, r);
+                        } else {
+                            bkmin += c_size;
+                            bkmax = min(bkmax + c_size, r);
+                        }
+                        sel = bkmax - 1;
+                        int cur = bkmin;
+                        if (cur <= bkmax) {
+                            bool stopped = false;
+                            if (cur < nN)
+                                cur = nN; // N entries never stop the scan
+                            if (cur <= bkmax && cur < nN + nZ) { // the zero entry
+                                if (rng.coin())
+                                    stopped = true;
+                                else
+                                    ++cur;
+                            }
+                            if (!stopped && cur <= bkmax) {
+                                if (cur < r)
+                                    stopped = true; // first S entry
+                                else
+                                    stopped = stop(stale_s[r]); // R[r_size] (stale)
+                            }
+                            if (stopped)
+                                sel = cur - 1;
+                        }
+                    }
+                    auto key_at = [&](int rank, bool& good) -> unsigned long long {
+                        if (rank == 0)
+                            return g1;
+                        if (rank == 1)
+                            return g2;
+                        if (rank == r - 1)
+                            return gx;
+                        if (nN > 0 && rank == nN - 1)
+                            return gxN;
+                        if (rank == nN)
+                            return nZ ? K0 : gnS;
+                        if (nZ && rank == nN + nZ)
+                            return gnS;
+                        good = false;
+                        return 0ull;
+                    };
+                    if (sel < 0) {
+                        k_sel = key_at(0, ok); // R[0]
+                    } else if (sel + 1 >= r) {
+                        k_sel = key_at(r - 1, ok); // R[selected] == R[r - 1]
+                    } else {
+                        k_sel = key_at(sel, ok);
+                        k_sel1 = key_at(sel + 1, ok);
+                    }
+                }
+                if (!ok) {
+                    rng.s = saved_rng; // the sort path redoes the scan
+                } else {
+                    alg_bytes += pb.row_bytes[k];
+                    const Float one = 1, two = 2;
+                    const Float middle = (two + one) / two;
+                    Float d = delta;
+                    const Float v_sel = key_value<Float>(k_sel, maximize);
+                    if (sel < 0) {
+                        d += (kappa / (one - kappa)) * (v_sel / two);
+                        misc_s[MS_SELMODE] = 0;
+                    } else if (sel + 1 >= r) {
+                        d += (kappa / (one - kappa)) * (v_sel * middle);
+                        misc_s[MS_SELMODE] = 1;
+                    } else {
+                        const Float v_sel1 = key_value<Float>(k_sel1, maximize);
+                        const Float old_pi = pi_s[k];
+                        const Float new_pi = old_pi + ((v_sel + v_sel1) / two);
+                        pi_s[k] = new_pi;
+                        d += (kappa / (one - kappa)) * (v_sel1 - v_sel);
+                        if (signbit(old_pi) != signbit(new_pi))
+                            misc_s[MS_PICH] = 1;
+                        misc_s[MS_SELMODE] = 2;
+                        *(unsigned long long*)(misc_s + MS_THR) = k_sel;
+                    }
+                    *d_s = d;
+                    misc_s[MS_FAST] = 1;
+                    // classes by sorted position, for the next stale read
+                    misc_s[MS_SEL] = nN;
+                    misc_s[MS_CNT] = nZ;
+                }
+            }
+            BXH_STAMP(10);
+            __syncthreads();
+            fast = misc_s[MS_FAST] != 0;
+        }
+        if (fast) {
+            BXH_STAMP(1);
+            // ---- affect without the sorted order ------------------------------
+            const int mode = misc_s[MS_SELMODE];
+            const unsigned long long thr = *(const unsigned long long*)(misc_s + MS_THR);
+            const Float d = *d_s;
+            const int nN = misc_s[MS_SEL], nZ = misc_s[MS_CNT];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int idx = tid + s2 * T;
+                if (idx < r) {
+                    const int j = col_s[idx];
+                    const int pe = pe_s[idx];
+                    bool up = mode == 1 || (mode == 2 && mykey[s2] <= thr);
+                    if (PM1 && pb.fac_csr[rs + idx] < 0)
+                        up = !up;
+                    const Float p = P[pe] * theta;
+                    if (up) {
+                        atomicOr(&x_s[j >> 5], 1u << (j & 31));
+                        P[pe] = p + d;
+                    } else {
+                        atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
+                        P[pe] = p - d;
+                    }
+                    // R[idx].value after the sort only matters through
+                    // stop_iterating: keep its class (N / zero / S)
+                    const Float repN = maximize ? (Float)1 : (Float)-1;
+                    stale_s[idx] = idx < nN ? repN : (idx < nN + nZ ? (Float)0 : -repN);
+                }
+            }
+            __syncthreads();
+            BXH_STAMP(6);
+            continue;
+        }
 
         // ---- calculator_sort: sort, then shuffle every run of equal values -
         if (r <= 2 * T && r <= 1024) {
