@@ -539,6 +539,10 @@ enum
     MS_TIE = 1,
     MS_PICH = 2,
     MS_CNT = 3,
+    MS_BMIN = 6,   // row constants fetched with the row descriptor
+    MS_BMAX = 7,
+    MS_BNEG = 12,
+    MS_RBYTES = 14, // double (8 bytes)
     MS_FAST = 4,   // 1: the row was resolved without sorting
     MS_SELMODE = 5, // 0: none up, 1: all up, 2: up iff key <= threshold
     MS_D = 8,      // Float d (8 bytes reserved)
@@ -913,6 +917,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const Float* cost = (const Float*)pb.cost;
 
     const Float kappa = (Float)a.kappa[inst];
+    // affect() evaluates kappa / (one - kappa) for every row; same operands,
+    // same quotient: computed once per sweep
+    const Float kfac = kappa / ((Float)1 - kappa);
     const Float delta = (Float)a.delta;
     const Float theta = (Float)a.theta;
     const Float obj_amp = (Float)a.obj_amp;
@@ -947,17 +954,67 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     prof.t = wall_clock64();
 #endif
 
+    // row ids and extents one row ahead (three dependent global loads
+    // otherwise sit at the head of every row)
+    auto row_at = [&](int it_) -> int {
+        return (a.order == 1) ? vlist[nrows - 1 - it_] : vlist[it_];
+    };
+    int k_next = nrows > 0 ? row_at(0) : 0;
+    int rs_next = nrows > 0 ? pb.row_ptr[k_next] : 0;
+    int re_next = nrows > 0 ? pb.row_ptr[k_next + 1] : 0;
+    // the next row's descriptor (column start / padded length, CSC slot and
+    // column of each element) travels in registers while this row is worked on
+    int2 d_cs[2];
+    int d_pe[2], d_col[2];
+    auto fetch_desc = [&](int rs_, int r_) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int idx = tid + s2 * T;
+            if (idx < r_) {
+                d_cs[s2] = pb.row_cs[rs_ + idx];
+                d_pe[s2] = pb.row_pos[rs_ + idx];
+                d_col[s2] = pb.row_col[rs_ + idx];
+            }
+        }
+    };
+    if (nrows > 0)
+        fetch_desc(rs_next, re_next - rs_next);
+
     for (int it = 0; it < nrows; ++it) {
-        const int k = (a.order == 1) ? vlist[nrows - 1 - it] : vlist[it];
-        const int rs = pb.row_ptr[k];
-        const int r = pb.row_ptr[k + 1] - rs;
+        const int k = k_next;
+        const int rs = rs_next;
+        const int r = re_next - rs_next;
 
         // ---- row descriptor -> LDS ----------------------------------------
-        for (int idx = tid; idx < r; idx += T) {
-            const int e = rs + idx;
-            cs_s[idx] = pb.row_cs[e];
-            pe_s[idx] = pb.row_pos[e];
-            col_s[idx] = pb.row_col[e];
+        if (r <= 2 * T) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int idx = tid + s2 * T;
+                if (idx < r) {
+                    cs_s[idx] = d_cs[s2];
+                    pe_s[idx] = d_pe[s2];
+                    col_s[idx] = d_col[s2];
+                }
+            }
+        } else {
+            for (int idx = tid; idx < r; idx += T) {
+                const int e = rs + idx;
+                cs_s[idx] = pb.row_cs[e];
+                pe_s[idx] = pb.row_pos[e];
+                col_s[idx] = pb.row_col[e];
+            }
+        }
+        if (it + 1 < nrows) {
+            k_next = row_at(it + 1);
+            rs_next = pb.row_ptr[k_next];
+            re_next = pb.row_ptr[k_next + 1];
+            fetch_desc(rs_next, re_next - rs_next);
+        }
+        if (tid == 64 % T) { // row constants of select_variables, off thread 0
+            misc_s[MS_BMIN] = pb.bmin[k];
+            misc_s[MS_BMAX] = pb.bmax[k];
+            misc_s[MS_BNEG] = pb.bneg[k];
+            *(double*)(misc_s + MS_RBYTES) = pb.row_bytes[k];
         }
         __syncthreads();
         BXH_STAMP(0);
@@ -1230,8 +1287,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                             return rng.coin();
                         return maximize ? v < 0 : v > 0;
                     };
-                    const int c_size = PM1 ? pb.bneg[k] : 0;
-                    int bkmin = pb.bmin[k], bkmax = pb.bmax[k];
+                    const int c_size = PM1 ? misc_s[MS_BNEG] : 0;
+                    int bkmin = misc_s[MS_BMIN], bkmax = misc_s[MS_BMAX];
                     if (kind == 0 || kind == 2 || bkmin == bkmax) {
                         sel = min(bkmin + c_size, r) - 1;
                     } else {
@@ -1292,23 +1349,23 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 if (!ok) {
                     rng.s = saved_rng; // the sort path redoes the scan
                 } else {
-                    alg_bytes += pb.row_bytes[k];
+                    alg_bytes += *(const double*)(misc_s + MS_RBYTES);
                     const Float one = 1, two = 2;
                     const Float middle = (two + one) / two;
                     Float d = delta;
                     const Float v_sel = key_value<Float>(k_sel, maximize);
                     if (sel < 0) {
-                        d += (kappa / (one - kappa)) * (v_sel / two);
+                        d += kfac * (v_sel / two);
                         misc_s[MS_SELMODE] = 0;
                     } else if (sel + 1 >= r) {
-                        d += (kappa / (one - kappa)) * (v_sel * middle);
+                        d += kfac * (v_sel * middle);
                         misc_s[MS_SELMODE] = 1;
                     } else {
                         const Float v_sel1 = key_value<Float>(k_sel1, maximize);
                         const Float old_pi = pi_s[k];
                         const Float new_pi = old_pi + ((v_sel + v_sel1) / two);
                         pi_s[k] = new_pi;
-                        d += (kappa / (one - kappa)) * (v_sel1 - v_sel);
+                        d += kfac * (v_sel1 - v_sel);
                         if (signbit(old_pi) != signbit(new_pi))
                             misc_s[MS_PICH] = 1;
                         misc_s[MS_SELMODE] = 2;
@@ -1388,7 +1445,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 
         // ---- thread 0: tie shuffle, select_variables, pi and d of affect ---
         if (tid == 0) {
-            alg_bytes += pb.row_bytes[k];
+            alg_bytes += *(const double*)(misc_s + MS_RBYTES);
             if (misc_s[MS_TIE]) {
                 int b0 = 0;
                 for (int i = 1; i <= r; ++i) {
@@ -1408,8 +1465,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 return maximize ? v < 0 : v > 0;
             };
 
-            const int c_size = PM1 ? pb.bneg[k] : 0;
-            int bkmin = pb.bmin[k], bkmax = pb.bmax[k];
+            const int c_size = PM1 ? misc_s[MS_BNEG] : 0;
+            int bkmin = misc_s[MS_BMIN], bkmax = misc_s[MS_BMAX];
             int sel;
             if (kind == 0 || kind == 2 || bkmin == bkmax) {
                 sel = min(bkmin + c_size, r) - 1;
@@ -1433,14 +1490,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             const Float middle = (two + one) / two;
             Float d = delta;
             if (sel < 0) {
-                d += (kappa / (one - kappa)) * (Rv(0) / two);
+                d += kfac * (Rv(0) / two);
             } else if (sel + 1 >= r) {
-                d += (kappa / (one - kappa)) * (Rv(sel) * middle);
+                d += kfac * (Rv(sel) * middle);
             } else {
                 const Float old_pi = pi_s[k];
                 const Float new_pi = old_pi + ((Rv(sel) + Rv(sel + 1)) / two);
                 pi_s[k] = new_pi;
-                d += (kappa / (one - kappa)) * (Rv(sel + 1) - Rv(sel));
+                d += kfac * (Rv(sel + 1) - Rv(sel));
                 if (signbit(old_pi) != signbit(new_pi))
                     misc_s[MS_PICH] = 1;
             }
