@@ -1,0 +1,235 @@
+// baryonyx_amd/host/c_api.cpp -- a small C surface over the C++ API so the
+// Python test / bench plumbing (ctypes) can drive baryonyx::make_problem,
+// solve and optimize without a C++ test runner.
+#include "private.hpp"
+
+#include <cstring>
+#include <sstream>
+
+using namespace baryonyx;
+
+extern "C" {
+
+struct bxc_params
+{
+    double time_limit, theta, delta, kappa_min, kappa_step, kappa_max, alpha;
+    double pushing_k_factor, pushing_objective_amplifier, init_policy_random, w;
+    long long limit;
+    unsigned seed;
+    int thread, pushes_limit, pushing_iteration_limit, init_population_size;
+    int order, float_type, init_policy, cost_norm, pre_order;
+    int device;
+    long long sweep_budget;
+};
+
+struct bxc_problem_info
+{
+    int status; // file_format_error_tag
+    int variables, equal, greater, less, nnz;
+    int maximize, problem_type, n_objective, n_quadratic, n_binary;
+    double objective_constant;
+};
+
+struct bxc_result
+{
+    int status; // result_status
+    int remaining_constraints, variables, constraints, n_solutions, valid;
+    long long loop;
+    double value, recomputed_value, duration;
+};
+
+BX_EXPORT void
+bxc_default_params(bxc_params* p)
+{
+    const solver_parameters d;
+    std::memset(p, 0, sizeof *p);
+    p->time_limit = d.time_limit;
+    p->theta = d.theta;
+    p->delta = d.delta;
+    p->kappa_min = d.kappa_min;
+    p->kappa_step = d.kappa_step;
+    p->kappa_max = d.kappa_max;
+    p->alpha = d.alpha;
+    p->pushing_k_factor = d.pushing_k_factor;
+    p->pushing_objective_amplifier = d.pushing_objective_amplifier;
+    p->init_policy_random = d.init_policy_random;
+    p->w = d.w;
+    p->limit = d.limit;
+    p->seed = d.seed;
+    p->thread = d.thread;
+    p->pushes_limit = d.pushes_limit;
+    p->pushing_iteration_limit = d.pushing_iteration_limit;
+    p->init_population_size = d.init_population_size;
+    p->order = static_cast<int>(d.order);
+    p->float_type = static_cast<int>(d.float_type);
+    p->init_policy = static_cast<int>(d.init_policy);
+    p->cost_norm = static_cast<int>(d.cost_norm);
+    p->pre_order = static_cast<int>(d.pre_order);
+}
+
+static context_ptr
+make_ctx(const bxc_params* p)
+{
+    auto ctx = make_context(3);
+    solver_parameters q;
+    q.time_limit = p->time_limit;
+    q.theta = p->theta;
+    q.delta = p->delta;
+    q.kappa_min = p->kappa_min;
+    q.kappa_step = p->kappa_step;
+    q.kappa_max = p->kappa_max;
+    q.alpha = p->alpha;
+    q.pushing_k_factor = p->pushing_k_factor;
+    q.pushing_objective_amplifier = p->pushing_objective_amplifier;
+    q.init_policy_random = p->init_policy_random;
+    q.w = p->w;
+    q.limit = static_cast<long>(p->limit);
+    q.seed = p->seed;
+    q.thread = p->thread;
+    q.pushes_limit = p->pushes_limit;
+    q.pushing_iteration_limit = p->pushing_iteration_limit;
+    q.init_population_size = p->init_population_size;
+    q.order = static_cast<solver_parameters::constraint_order>(p->order);
+    q.float_type = static_cast<solver_parameters::floating_point_type>(p->float_type);
+    q.init_policy = static_cast<solver_parameters::init_policy_type>(p->init_policy);
+    q.cost_norm = static_cast<solver_parameters::cost_norm_type>(p->cost_norm);
+    q.pre_order = static_cast<solver_parameters::pre_constraint_order>(p->pre_order);
+    context_set_solver_parameters(ctx, q);
+    context_set_parameters(ctx, "device", std::to_string(p->device));
+    if (p->sweep_budget > 0)
+        context_set_parameters(ctx, "sweep-budget", std::to_string(p->sweep_budget));
+    return ctx;
+}
+
+// make_problem on a file; fills `info`.
+BX_EXPORT int
+bxc_parse(const char* path, bxc_problem_info* info)
+{
+    auto ctx = make_context(3);
+    const raw_problem pb = make_problem(ctx, path);
+    std::memset(info, 0, sizeof *info);
+    info->status = static_cast<int>(pb.status);
+    if (!pb)
+        return 0;
+    info->variables = static_cast<int>(pb.vars.values.size());
+    info->equal = static_cast<int>(pb.equal_constraints.size());
+    info->greater = static_cast<int>(pb.greater_constraints.size());
+    info->less = static_cast<int>(pb.less_constraints.size());
+    for (const auto* v : { &pb.equal_constraints, &pb.greater_constraints, &pb.less_constraints })
+        for (const auto& c : *v)
+            info->nnz += static_cast<int>(c.elements.size());
+    info->maximize = pb.type == objective_function_type::maximize;
+    info->problem_type = static_cast<int>(problem(pb).problem_type);
+    info->n_objective = static_cast<int>(pb.objective.elements.size());
+    info->n_quadratic = static_cast<int>(pb.objective.qelements.size());
+    for (const auto& v : pb.vars.values)
+        info->n_binary += v.type == variable_type::binary;
+    info->objective_constant = pb.objective.value;
+    return 0;
+}
+
+// The merged constraints (CSR) and objective of a file, for feeding another
+// solver with exactly what the device gets.  Two calls: buffers null -> sizes.
+BX_EXPORT int
+bxc_merged(const char* path,
+           int pre_order,
+           int* m,
+           int* n,
+           int* nnz,
+           int* n_obj,
+           int* row_ptr,
+           int* col,
+           int* factor,
+           int* cmin,
+           int* cmax,
+           int* obj_var,
+           double* obj_factor,
+           double* obj_constant,
+           int* maximize,
+           int* problem_type)
+{
+    auto ctx = make_context(3);
+    solver_parameters q;
+    q.pre_order = static_cast<solver_parameters::pre_constraint_order>(pre_order);
+    context_set_solver_parameters(ctx, q);
+    const raw_problem raw = make_problem(ctx, path);
+    if (!raw)
+        return -1;
+    const problem pb(raw);
+    std::vector<merged_constraint> csts;
+    try {
+        csts = make_merged_constraints(*ctx, pb);
+    } catch (...) {
+        return -2;
+    }
+    int count = 0;
+    for (const auto& c : csts)
+        count += static_cast<int>(c.elements.size());
+    *m = static_cast<int>(csts.size());
+    *n = static_cast<int>(pb.vars.values.size());
+    *nnz = count;
+    *n_obj = static_cast<int>(pb.objective.elements.size());
+    *obj_constant = pb.objective.value;
+    *maximize = pb.type == objective_function_type::maximize;
+    *problem_type = static_cast<int>(pb.problem_type);
+    if (!row_ptr)
+        return 0;
+    int e = 0;
+    row_ptr[0] = 0;
+    for (int k = 0; k != *m; ++k) {
+        for (const auto& el : csts[k].elements) {
+            col[e] = el.variable_index;
+            factor[e] = el.factor;
+            ++e;
+        }
+        row_ptr[k + 1] = e;
+        cmin[k] = csts[k].min;
+        cmax[k] = csts[k].max;
+    }
+    for (int i = 0; i != *n_obj; ++i) {
+        obj_var[i] = pb.objective.elements[i].variable_index;
+        obj_factor[i] = pb.objective.elements[i].factor;
+    }
+    return 0;
+}
+
+// baryonyx::solve (mode 0) or baryonyx::optimize (mode 1) on a file.
+BX_EXPORT int
+bxc_run(const char* path, int mode, const bxc_params* p, bxc_result* out, signed char* x_out, char* err, int errlen)
+{
+    std::memset(out, 0, sizeof *out);
+    try {
+        auto ctx = make_ctx(p);
+        const raw_problem pb = make_problem(ctx, path);
+        if (!pb) {
+            std::snprintf(err, static_cast<size_t>(errlen), "parse error %d", static_cast<int>(pb.status));
+            return -1;
+        }
+        const result r = mode == 0 ? solve(ctx, pb) : optimize(ctx, pb);
+        out->status = static_cast<int>(r.status);
+        out->remaining_constraints = r.remaining_constraints;
+        out->variables = r.variables;
+        out->constraints = r.constraints;
+        out->n_solutions = static_cast<int>(r.solutions.size());
+        out->loop = r.loop;
+        out->duration = r.duration;
+        if (!r.solutions.empty()) {
+            out->value = r.solutions.front().value;
+            if (x_out)
+                for (size_t i = 0; i != r.solutions.front().variables.size(); ++i)
+                    x_out[i] = r.solutions.front().variables[i];
+        }
+        out->valid = is_valid_solution(pb, r) ? 1 : 0;
+        if (r && !r.solutions.empty())
+            out->recomputed_value = compute_solution(pb, r);
+        return 0;
+    } catch (const solver_failure& e) {
+        std::snprintf(err, static_cast<size_t>(errlen), "solver_failure %d", static_cast<int>(e.failure()));
+        return -2;
+    } catch (const std::exception& e) {
+        std::snprintf(err, static_cast<size_t>(errlen), "%s", e.what());
+        return -3;
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,509 @@
+// baryonyx_amd/host/lp_parser.cpp -- CPLEX-LP reader with the grammar the
+// reference accepts (lib/src/parser.cpp:1064-1257): objective sense, optional
+// label, linear terms and `[ ... ] / 2` quadratic terms, `subject to`
+// constraints `label: terms (<=|>=|=) rhs`, then `bounds`, `binary`,
+// `general`, `end`.  Variables are numbered by first appearance; repeated
+// variables inside one expression are accumulated.
+#include "private.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <optional>
+#include <unordered_map>
+
+namespace baryonyx {
+namespace {
+
+bool
+ieq(std::string_view a, const char* b)
+{
+    size_t i = 0;
+    for (; i < a.size() && b[i]; ++i)
+        if (std::tolower(static_cast<unsigned char>(a[i])) != b[i])
+            return false;
+    return i == a.size() && b[i] == '\0';
+}
+
+bool
+is_sep(char c)
+{
+    return c == '*' || c == '/' || c == '+' || c == '-' || c == '<' ||
+           c == '>' || c == '=' || c == ':' || c == '[' || c == ']' || c == '^';
+}
+
+bool
+name_start(char c)
+{
+    return std::isalpha(static_cast<unsigned char>(c)) || c == '_' || c == '!' ||
+           c == '"' || c == '#' || c == '$' || c == '%' || c == '&' || c == '(' ||
+           c == ')' || c == ',' || c == ';' || c == '?' || c == '@' || c == '{' ||
+           c == '}' || c == '~' || c == '\'';
+}
+
+// Token stream: whitespace separated words, `\` comments, words split at
+// operator characters and between a leading number and a following name.
+struct lexer
+{
+    std::vector<std::string> tok;
+    size_t pos = 0;
+
+    explicit lexer(std::istream& is)
+    {
+        std::string line;
+        while (std::getline(is, line)) {
+            size_t i = 0;
+            const size_t n = line.size();
+            while (i < n) {
+                const char c = line[i];
+                if (c == '\\')
+                    break;
+                if (std::isspace(static_cast<unsigned char>(c))) {
+                    ++i;
+                    continue;
+                }
+                if (is_sep(c)) {
+                    tok.emplace_back(1, c);
+                    ++i;
+                    continue;
+                }
+                size_t j = i;
+                if (std::isdigit(static_cast<unsigned char>(c)) || c == '.') {
+                    // number: digits [. digits] [e[+-]digits]
+                    while (j < n && (std::isdigit(static_cast<unsigned char>(line[j])) ||
+                                     line[j] == '.'))
+                        ++j;
+                    if (j < n && (line[j] == 'e' || line[j] == 'E')) {
+                        size_t k = j + 1;
+                        if (k < n && (line[k] == '+' || line[k] == '-'))
+                            ++k;
+                        if (k < n && std::isdigit(static_cast<unsigned char>(line[k]))) {
+                            while (k < n && std::isdigit(static_cast<unsigned char>(line[k])))
+                                ++k;
+                            j = k;
+                        }
+                    }
+                } else {
+                    while (j < n && !std::isspace(static_cast<unsigned char>(line[j])) &&
+                           !is_sep(line[j]) && line[j] != '\\')
+                        ++j;
+                }
+                tok.emplace_back(line.substr(i, j - i));
+                i = j;
+            }
+        }
+    }
+
+    std::string_view peek(size_t k = 0) const
+    {
+        return pos + k < tok.size() ? std::string_view(tok[pos + k])
+                                    : std::string_view();
+    }
+    void pop(size_t k = 1) { pos += k; }
+    bool end() const { return pos >= tok.size(); }
+};
+
+bool
+is_number(std::string_view t)
+{
+    return !t.empty() &&
+           (std::isdigit(static_cast<unsigned char>(t[0])) || t[0] == '.');
+}
+
+bool
+is_name(std::string_view t)
+{
+    return !t.empty() && name_start(t[0]);
+}
+
+int
+keyword_len(const lexer& lx)
+{
+    const auto a = lx.peek(0), b = lx.peek(1);
+    auto colon = [&](size_t k) { return lx.peek(k) == ":" ? 1 : 0; };
+    if (ieq(a, "st") || ieq(a, "st.") || ieq(a, "s.t") || ieq(a, "s.t."))
+        return 1 + colon(1);
+    if ((ieq(a, "subject") && ieq(b, "to")) || (ieq(a, "sush") && ieq(b, "that")) ||
+        (ieq(a, "such") && ieq(b, "that")))
+        return 2 + colon(2);
+    if (ieq(a, "bounds") || ieq(a, "bound") || ieq(a, "binary") ||
+        ieq(a, "binaries") || ieq(a, "bin") || ieq(a, "general") ||
+        ieq(a, "generals") || ieq(a, "gen") || ieq(a, "end"))
+        return 1 + colon(1);
+    return 0;
+}
+
+struct term
+{
+    double factor;
+    std::string_view name; // empty: a constant
+};
+
+// [+|-] [number] [name]
+std::optional<term>
+read_term(lexer& lx)
+{
+    double sign = 1.0;
+    bool any = false;
+    while (lx.peek() == "+" || lx.peek() == "-") {
+        if (lx.peek() == "-")
+            sign = -sign;
+        lx.pop();
+        any = true;
+    }
+    double value = 1.0;
+    bool has_number = false;
+    if (is_number(lx.peek())) {
+        value = std::strtod(std::string(lx.peek()).c_str(), nullptr);
+        lx.pop();
+        has_number = true;
+    }
+    if (is_name(lx.peek()) && keyword_len(lx) == 0) {
+        term t{ sign * value, lx.peek() };
+        lx.pop();
+        return t;
+    }
+    if (has_number)
+        return term{ sign * value, std::string_view() };
+    (void)any;
+    return std::nullopt;
+}
+
+std::optional<operator_type>
+read_operator(lexer& lx)
+{
+    const auto a = lx.peek(0), b = lx.peek(1);
+    if (a == "<") {
+        lx.pop(b == "=" ? 2 : 1);
+        return operator_type::less;
+    }
+    if (a == ">") {
+        lx.pop(b == "=" ? 2 : 1);
+        return operator_type::greater;
+    }
+    if (a == "=") {
+        if (b == "<") {
+            lx.pop(2);
+            return operator_type::less;
+        }
+        if (b == ">") {
+            lx.pop(2);
+            return operator_type::greater;
+        }
+        lx.pop(b == "=" ? 2 : 1);
+        return operator_type::equal;
+    }
+    return std::nullopt;
+}
+
+std::optional<double>
+read_signed_number(lexer& lx)
+{
+    double sign = 1.0;
+    if (lx.peek() == "+" || lx.peek() == "-") {
+        if (lx.peek() == "-")
+            sign = -1.0;
+        lx.pop();
+    }
+    if (ieq(lx.peek(), "inf") || ieq(lx.peek(), "infinity")) {
+        lx.pop();
+        return sign * std::numeric_limits<double>::infinity();
+    }
+    if (!is_number(lx.peek()))
+        return std::nullopt;
+    const double v = std::strtod(std::string(lx.peek()).c_str(), nullptr);
+    lx.pop();
+    return sign * v;
+}
+
+struct builder
+{
+    raw_problem pb;
+    std::unordered_map<std::string, int> cache;
+
+    builder() { pb.strings = std::make_shared<string_buffer>(); }
+
+    int variable(std::string_view name)
+    {
+        auto it = cache.find(std::string(name));
+        if (it != cache.end())
+            return it->second;
+        const int id = static_cast<int>(cache.size());
+        cache.emplace(std::string(name), id);
+        pb.vars.names.emplace_back(pb.strings->append(name));
+        pb.vars.values.emplace_back(0, std::numeric_limits<int>::max(), variable_type::real);
+        return id;
+    }
+    int find(std::string_view name) const
+    {
+        auto it = cache.find(std::string(name));
+        return it == cache.end() ? -1 : it->second;
+    }
+};
+
+int
+to_bound(double v)
+{
+    if (v == -std::numeric_limits<double>::infinity())
+        return std::numeric_limits<int>::min();
+    if (v == std::numeric_limits<double>::infinity())
+        return std::numeric_limits<int>::max();
+    return static_cast<int>(v);
+}
+
+file_format_error_tag
+parse(lexer& lx, builder& b)
+{
+    using tag = file_format_error_tag;
+
+    if (ieq(lx.peek(), "maximize") || ieq(lx.peek(), "maximum") || ieq(lx.peek(), "max"))
+        b.pb.type = objective_function_type::maximize;
+    else if (ieq(lx.peek(), "minimize") || ieq(lx.peek(), "minimum") || ieq(lx.peek(), "min"))
+        b.pb.type = objective_function_type::minimize;
+    else
+        return tag::bad_objective_function_type;
+    lx.pop();
+
+    if (keyword_len(lx) == 0 && lx.peek(1) == ":")
+        lx.pop(2); // objective label
+
+    // ---- objective ---------------------------------------------------------
+    while (!lx.end() && keyword_len(lx) == 0) {
+        const bool quad = lx.peek() == "[" ||
+                          ((lx.peek() == "+" || lx.peek() == "-") && lx.peek(1) == "[");
+        if (quad) {
+            double sign = 1.0;
+            if (lx.peek() == "-")
+                sign = -1.0;
+            if (lx.peek() != "[")
+                lx.pop();
+            lx.pop(); // [
+            while (!lx.end() && lx.peek() != "]") {
+                auto t = read_term(lx);
+                if (!t || t->name.empty())
+                    return tag::bad_objective_quadratic;
+                const int a = b.variable(t->name);
+                int c = -1;
+                if (lx.peek() == "*") {
+                    if (!is_name(lx.peek(1)))
+                        return tag::bad_objective_quadratic;
+                    c = b.variable(lx.peek(1));
+                    lx.pop(2);
+                } else if (lx.peek() == "^") {
+                    if (lx.peek(1) != "2")
+                        return tag::bad_objective_quadratic;
+                    c = a;
+                    lx.pop(2);
+                } else {
+                    return tag::bad_objective_quadratic;
+                }
+                auto& q = b.pb.objective.qelements;
+                auto it = std::find_if(q.begin(), q.end(), [a, c](const auto& e) {
+                    return (e.variable_index_a == a && e.variable_index_b == c) ||
+                           (e.variable_index_a == c && e.variable_index_b == a);
+                });
+                if (it == q.end())
+                    q.emplace_back(t->factor * sign / 2.0, a, c);
+                else
+                    it->factor += t->factor * sign / 2.0;
+            }
+            if (lx.peek() != "]")
+                return tag::bad_objective_quadratic;
+            lx.pop();
+            if (lx.peek() == "/" && lx.peek(1) == "2")
+                lx.pop(2);
+            else
+                return tag::bad_objective_quadratic;
+            continue;
+        }
+        auto t = read_term(lx);
+        if (!t)
+            return tag::bad_objective;
+        if (t->name.empty()) {
+            b.pb.objective.value += t->factor;
+        } else {
+            const int id = b.variable(t->name);
+            auto& el = b.pb.objective.elements;
+            auto it = std::find_if(el.begin(), el.end(), [id](const auto& e) {
+                return e.variable_index == id;
+            });
+            if (it == el.end())
+                el.emplace_back(t->factor, id);
+            else
+                it->factor += t->factor;
+        }
+    }
+
+    // ---- constraints -------------------------------------------------------
+    {
+        const auto a = lx.peek();
+        const bool st = ieq(a, "st") || ieq(a, "st.") || ieq(a, "s.t") || ieq(a, "s.t.") ||
+                        ieq(a, "subject") || ieq(a, "sush") || ieq(a, "such");
+        if (st) {
+            lx.pop(static_cast<size_t>(keyword_len(lx)));
+            int next_id = 0;
+            while (!lx.end() && keyword_len(lx) == 0) {
+                std::string_view label;
+                if (is_name(lx.peek()) && lx.peek(1) == ":") {
+                    label = b.pb.strings->append(lx.peek());
+                    lx.pop(2);
+                }
+                std::vector<function_element> elements;
+                bool first = true;
+                while (!lx.end() && lx.peek() != "<" && lx.peek() != ">" && lx.peek() != "=") {
+                    auto t = read_term(lx);
+                    if (!t || t->name.empty())
+                        return tag::bad_constraint;
+                    const int id = b.variable(t->name);
+                    auto it = std::find_if(elements.begin(), elements.end(),
+                                           [id](const auto& e) { return e.variable_index == id; });
+                    if (it == elements.end())
+                        elements.emplace_back(static_cast<int>(t->factor), id);
+                    else
+                        it->factor += static_cast<int>(t->factor);
+                    first = false;
+                }
+                if (first)
+                    return tag::bad_constraint;
+                auto op = read_operator(lx);
+                if (!op)
+                    return tag::bad_constraint;
+                auto rhs = read_signed_number(lx);
+                if (!rhs)
+                    return tag::bad_constraint;
+                const int value = static_cast<int>(*rhs);
+                switch (*op) {
+                case operator_type::equal:
+                    b.pb.equal_constraints.emplace_back(label, std::move(elements), value, next_id++);
+                    break;
+                case operator_type::greater:
+                    b.pb.greater_constraints.emplace_back(label, std::move(elements), value, next_id++);
+                    break;
+                case operator_type::less:
+                    b.pb.less_constraints.emplace_back(label, std::move(elements), value, next_id++);
+                    break;
+                }
+            }
+        }
+    }
+
+    // ---- bounds ------------------------------------------------------------
+    if (ieq(lx.peek(), "bounds") || ieq(lx.peek(), "bound")) {
+        lx.pop(static_cast<size_t>(keyword_len(lx)));
+        while (!lx.end() && keyword_len(lx) == 0) {
+            double lo = 0.0, hi = std::numeric_limits<double>::infinity();
+            std::string_view name;
+            if (is_name(lx.peek())) {
+                name = lx.peek();
+                lx.pop();
+                if (ieq(lx.peek(), "free")) {
+                    lx.pop();
+                    lo = -std::numeric_limits<double>::infinity();
+                } else if (auto op = read_operator(lx); op) {
+                    auto v = read_signed_number(lx);
+                    if (!v)
+                        return tag::bad_bound;
+                    if (*op == operator_type::less)
+                        hi = *v;
+                    else if (*op == operator_type::greater)
+                        lo = *v;
+                    else
+                        lo = hi = *v;
+                } else {
+                    lo = -std::numeric_limits<double>::infinity();
+                }
+            } else {
+                auto l = read_signed_number(lx);
+                if (!l)
+                    return tag::bad_bound;
+                auto op = read_operator(lx);
+                if (!op || !is_name(lx.peek()))
+                    return tag::bad_bound;
+                name = lx.peek();
+                lx.pop();
+                if (*op == operator_type::less)
+                    lo = *l;
+                else if (*op == operator_type::greater)
+                    hi = *l;
+                else
+                    lo = hi = *l;
+                if (auto op2 = read_operator(lx); op2) {
+                    auto r = read_signed_number(lx);
+                    if (!r)
+                        return tag::bad_bound;
+                    if (*op2 == operator_type::less)
+                        hi = *r;
+                    else if (*op2 == operator_type::greater)
+                        lo = *r;
+                }
+                if (lo > hi)
+                    return tag::bad_bound;
+            }
+            const int id = b.find(name);
+            if (id < 0)
+                return tag::bad_bound;
+            b.pb.vars.values[id].min = to_bound(lo);
+            b.pb.vars.values[id].max = to_bound(hi);
+        }
+    }
+
+    // ---- binary / general ---------------------------------------------------
+    if (ieq(lx.peek(), "binary") || ieq(lx.peek(), "binaries") || ieq(lx.peek(), "bin")) {
+        lx.pop(static_cast<size_t>(keyword_len(lx)));
+        while (!lx.end() && keyword_len(lx) == 0) {
+            const int id = b.find(lx.peek());
+            if (id < 0)
+                return tag::bad_binary;
+            b.pb.vars.values[id] = variable_value(0, 1, variable_type::binary);
+            lx.pop();
+        }
+    }
+    if (ieq(lx.peek(), "general") || ieq(lx.peek(), "generals") || ieq(lx.peek(), "gen")) {
+        lx.pop(static_cast<size_t>(keyword_len(lx)));
+        while (!lx.end() && keyword_len(lx) == 0) {
+            const int id = b.find(lx.peek());
+            if (id < 0)
+                return tag::bad_general;
+            b.pb.vars.values[id].type = variable_type::general;
+            lx.pop();
+        }
+    }
+    if (ieq(lx.peek(), "end")) {
+        lx.pop(static_cast<size_t>(keyword_len(lx)));
+        return lx.end() ? tag::success : tag::bad_end_of_file;
+    }
+    return tag::bad_end;
+}
+
+} // namespace
+
+raw_problem
+make_problem(const context& /*ctx*/, std::istream& is) noexcept
+{
+    try {
+        lexer lx(is);
+        builder b;
+        const auto st = parse(lx, b);
+        if (st != file_format_error_tag::success)
+            return raw_problem(st);
+        return std::move(b.pb);
+    } catch (...) {
+        return raw_problem(file_format_error_tag::bad_end_of_file);
+    }
+}
+
+raw_problem
+make_problem(const context_ptr& ctx, const std::string& filename)
+{
+    if (!ctx)
+        return raw_problem(file_format_error_tag::empty_context);
+    std::ifstream ifs(filename);
+    if (!ifs.is_open())
+        return raw_problem(file_format_error_tag::file_not_found);
+    return make_problem(*ctx, ifs);
+}
+
+} // namespace baryonyx

@@ -1,0 +1,92 @@
+// baryonyx_amd/host/private.hpp -- internals of the C++ host library that
+// keeps baryonyx's public API (include/baryonyx/core) and drives the HIP
+// device layer (include/bxh.h).  Host code is C++ like the reference's; the
+// only native dependency is libbxh.so.
+#ifndef BARYONYX_AMD_HOST_PRIVATE_HPP
+#define BARYONYX_AMD_HOST_PRIVATE_HPP
+
+#include <baryonyx/core>
+
+#include <chrono>
+#include <cstdio>
+#include <istream>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace baryonyx {
+
+// The engine every subsystem shares, lib/src/itm-common.hpp:45.
+using random_engine = std::default_random_engine;
+
+// lib/src/private.hpp: parameters, the `method` string, the three callbacks
+// and a log level.
+struct context
+{
+    explicit context(int verbose_level)
+      : log_priority(verbose_level)
+    {}
+    solver_parameters parameters;
+    std::string method;
+    solver_started_cb start;
+    solver_updated_cb update;
+    solver_finished_cb finish;
+    int log_priority = 6;
+    int device = 0; // HIP device of the batch (context_set_parameters("device"))
+    long sweep_budget = 0; // > 0: optimize() also stops after that many
+                           // lock-step sweeps (context_set_parameters("sweep-budget"))
+};
+
+template<typename... Args>
+inline void
+info(const context& ctx, const char* fmt, Args... args)
+{
+    if (ctx.log_priority >= 6)
+        std::fprintf(stdout, fmt, args...);
+}
+
+// Internal problem: the raw problem plus what the preprocessor fixed
+// (lib/src/problem.hpp:44-166).
+struct problem
+{
+    problem() = default;
+    explicit problem(const raw_problem& pb);
+
+    string_buffer_ptr strings;
+    objective_function objective;
+    std::vector<constraint> equal_constraints;
+    std::vector<constraint> greater_constraints;
+    std::vector<constraint> less_constraints;
+    variables vars;
+    affected_variables affected_vars;
+    objective_function_type type = objective_function_type::maximize;
+    problem_solver_type problem_type = problem_solver_type::equalities_01;
+
+    problem_solver_type which_problem_type() const noexcept;
+};
+
+raw_problem make_problem(const context& ctx, std::istream& is) noexcept;
+problem unpreprocess(const context& ctx, const raw_problem& pb);
+
+// One merged row b_min <= sum a x <= b_max (lib/src/itm-common.hpp:55-71).
+struct merged_constraint
+{
+    std::vector<function_element> elements;
+    int min;
+    int max;
+    int id;
+};
+std::vector<merged_constraint> make_merged_constraints(const context& ctx,
+                                                      const problem& pb);
+
+bool is_valid_solution(const problem& pb, const std::vector<var_value>& x);
+double compute_solution(const problem& pb, const std::vector<var_value>& x);
+
+namespace itm {
+result solve(const context& ctx, const problem& pb);
+result optimize(const context& ctx, const problem& pb);
+}
+
+} // namespace baryonyx
+
+#endif

@@ -1,0 +1,137 @@
+"""ctypes binding of the C++ host library (baryonyx_amd/host/libbaryonyx_amd.so),
+which exposes baryonyx::make_problem / solve / optimize through a small C
+surface (host/c_api.cpp).  Plumbing for tests and bench.py."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST = os.path.join(_HERE, "host")
+LIB_PATH = os.path.join(HOST, "libbaryonyx_amd.so")
+SOURCES = ["lp_parser.cpp", "problem.cpp", "itm_gpu.cpp", "api.cpp", "c_api.cpp"]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "time_limit theta delta kappa_min kappa_step kappa_max alpha pushing_k_factor "
+        "pushing_objective_amplifier init_policy_random w").split()] + [
+        ("limit", C.c_longlong), ("seed", C.c_uint), ("thread", C.c_int),
+        ("pushes_limit", C.c_int), ("pushing_iteration_limit", C.c_int),
+        ("init_population_size", C.c_int), ("order", C.c_int), ("float_type", C.c_int),
+        ("init_policy", C.c_int), ("cost_norm", C.c_int), ("pre_order", C.c_int),
+        ("device", C.c_int), ("sweep_budget", C.c_longlong)]
+
+
+class ProblemInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "status variables equal greater less nnz maximize problem_type n_objective "
+        "n_quadratic n_binary").split()] + [("objective_constant", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "status remaining_constraints variables constraints n_solutions valid").split()] + [
+        ("loop", C.c_longlong), ("value", C.c_double), ("recomputed_value", C.c_double),
+        ("duration", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(HOST, s) for s in SOURCES] + [os.path.join(HOST, "private.hpp")]
+    bxh = os.path.join(_HERE, "csrc", "libbxh.so")
+    stale = force or not os.path.exists(LIB_PATH)
+    if not stale:
+        t = os.path.getmtime(LIB_PATH)
+        stale = any(os.path.getmtime(s) > t for s in srcs) or os.path.getmtime(bxh) > t
+    if stale:
+        subprocess.check_call(
+            ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+             "-I" + os.path.join(_HERE, "..", "include"), "-o", LIB_PATH,
+             *[os.path.join(HOST, s) for s in SOURCES],
+             "-L" + os.path.join(_HERE, "csrc"), "-lbxh", "-Wl,-rpath,$ORIGIN/../csrc"])
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        L.bxc_default_params.argtypes = [C.POINTER(Params)]
+        L.bxc_parse.argtypes = [C.c_char_p, C.POINTER(ProblemInfo)]
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        L.bxc_merged.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, dp, dp, ip, ip]
+        L.bxc_run.argtypes = [C.c_char_p, C.c_int, C.POINTER(Params), C.POINTER(Result),
+                              C.POINTER(C.c_byte), C.c_char_p, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().bxc_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def parse(path) -> ProblemInfo:
+    info = ProblemInfo()
+    lib().bxc_parse(os.fsencode(path), C.byref(info))
+    return info
+
+
+def merged(path, pre_order=0):
+    """The merged constraints + linear objective of an LP file as a
+    baryonyx_amd.synth.Instance (what a Solver constructor receives)."""
+    from .synth import Instance
+
+    L = lib()
+    m, n, nnz, nobj, mx, pt = (C.c_int() for _ in range(6))
+    const = C.c_double()
+    rc = L.bxc_merged(os.fsencode(path), pre_order, m, n, nnz, nobj, None, None, None, None,
+                      None, None, None, C.byref(const), mx, pt)
+    if rc != 0:
+        raise RuntimeError(f"bxc_merged({path}) -> {rc}")
+    row_ptr = np.zeros(m.value + 1, np.int32)
+    col = np.zeros(nnz.value, np.int32)
+    fac = np.zeros(nnz.value, np.int32)
+    cmin = np.zeros(m.value, np.int32)
+    cmax = np.zeros(m.value, np.int32)
+    ov = np.zeros(nobj.value, np.int32)
+    of = np.zeros(nobj.value, np.float64)
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    rc = L.bxc_merged(os.fsencode(path), pre_order, m, n, nnz, nobj,
+                      row_ptr.ctypes.data_as(ip), col.ctypes.data_as(ip), fac.ctypes.data_as(ip),
+                      cmin.ctypes.data_as(ip), cmax.ctypes.data_as(ip), ov.ctypes.data_as(ip),
+                      of.ctypes.data_as(dp), C.byref(const), mx, pt)
+    assert rc == 0
+    kind = {0: 0, 1: 2, 2: 4, 3: 1, 4: 3, 5: 4}[pt.value]  # problem_solver_type -> bxh_kind
+    return Instance(m=m.value, n=n.value, row_ptr=row_ptr, col=col, factor=fac, cmin=cmin,
+                    cmax=cmax, obj_var=ov, obj_factor=of, obj_constant=const.value,
+                    maximize=bool(mx.value), kind=kind, name=os.path.basename(path))
+
+
+def run(path, mode=0, params=None):
+    """baryonyx::solve (mode 0) / optimize (mode 1) on an LP file through the
+    C++ host library; returns (Result, x as int8 array)."""
+    L = lib()
+    p = params or default_params()
+    info = parse(path)
+    x = np.zeros(max(info.variables, 1), np.int8)
+    res = Result()
+    err = C.create_string_buffer(256)
+    rc = L.bxc_run(os.fsencode(path), mode, C.byref(p), C.byref(res),
+                   x.ctypes.data_as(C.POINTER(C.c_byte)), err, 256)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return res, x

@@ -240,3 +240,32 @@ def config_c2(cost_kind="int"):
 
 def config_c3(cost_kind="int"):
     return make_spp(426, 7195, 0.017, cost_kind, seed=4)
+
+
+def write_lp(inst: Instance, path: str) -> None:
+    """Write an Instance as a CPLEX-LP file (one row per merged constraint:
+    `=` when min == max, `>=` / `<=` for the finite side(s))."""
+    with open(path, "w") as f:
+        f.write("maximize\n" if inst.maximize else "minimize\n")
+        terms = [f"{'+' if c >= 0 else '-'} {abs(c):.17g} x{j}" for j, c in zip(inst.obj_var, inst.obj_factor)]
+        for i in range(0, len(terms), 8):
+            f.write(" " + " ".join(terms[i : i + 8]) + "\n")
+        f.write("subject to\n")
+        for k in range(inst.m):
+            s = slice(inst.row_ptr[k], inst.row_ptr[k + 1])
+            lhs = " ".join(f"{'+' if a >= 0 else '-'} {abs(int(a))} x{j}" if abs(a) != 1
+                           else f"{'+' if a > 0 else '-'} x{j}"
+                           for a, j in zip(inst.factor[s], inst.col[s]))
+            lo, hi = int(inst.cmin[k]), int(inst.cmax[k])
+            if lo == hi:
+                f.write(f"c{k}: {lhs} = {lo}\n")
+            else:
+                if lo > INT_MIN:
+                    f.write(f"c{k}g: {lhs} >= {lo}\n")
+                if hi < INT_MAX:
+                    f.write(f"c{k}l: {lhs} <= {hi}\n")
+        f.write("binary\n")
+        names = [f"x{j}" for j in range(inst.n)]
+        for i in range(0, inst.n, 16):
+            f.write(" " + " ".join(names[i : i + 16]) + "\n")
+        f.write("end\n")

@@ -1,0 +1,75 @@
+"""CPU: the C++ host library's LP reader against what the reference's own io
+tests expect of the fixture files (lib/test/io.cpp:661-726) and of a few
+inline problems of lib/test/solve.cpp."""
+import os
+
+import pytest
+
+from baryonyx_amd import host_ffi as H
+
+LP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lp")
+MIN, MAX = 0, 1
+
+
+def lp(name):
+    return os.path.join(LP, name)
+
+
+def test_geom_30a():
+    i = H.parse(lp("geom-30a-3-ext_1000_support.lp"))
+    assert i.status == 0 and i.maximize == MIN
+    assert i.variables == 819 and i.n_binary == 90
+
+
+def test_general():
+    i = H.parse(lp("general.lp"))
+    assert i.status == 0 and i.maximize == MIN and i.variables == 3 and i.n_binary == 0
+
+
+def test_sudoku_and_queens():
+    assert H.parse(lp("sudoku.lp")).variables == 81
+    q = H.parse(lp("8_queens_puzzle.lp"))
+    assert q.variables == 64 and q.n_binary == 64
+
+
+@pytest.mark.parametrize("name,ptype", [
+    ("assignment_problem_1.lp", 0), ("assignment_problem_2.lp", 0), ("assignment_problem_3.lp", 0),
+    ("8_queens_puzzle.lp", 3), ("prepro.lp", 4),
+    ("negative-coeff.lp", 1), ("negative-coeff2.lp", 1), ("negative-coeff3.lp", 1),
+    ("small4.lp", 1), ("geom-30a-3-ext_1000_support.lp", 1),
+    ("flat30-7.lp", 4), ("uf50-0448.lp", 4), ("aim-50-1_6-yes1-2.lp", 4), ("negative-coeff4.lp", 4),
+])
+def test_solver_family_per_fixture(name, ptype):
+    """which itm-solver-* each fixture is routed to
+    (problem_solver_type: 0 eq01, 1 eq101, 3 ineq01, 4 ineq101)."""
+    assert H.parse(lp(name)).problem_type == ptype
+
+
+def test_inline_problems(tmp_path):
+    p = tmp_path / "real_cost.lp"  # lib/test/solve.cpp:258-271
+    p.write_text("minimize\n- 0.1 a - 0.5 b - 0.9 c - 1e-7 d\nSubject to:\n-a -b -c <= -1\n"
+                 "-a -b -c >= -3\n-a -c >= -2\n-a -c <= -1\na + c >= 1\n+ b + c +d >= 2\n"
+                 "Binaries\na b c d\nEnd\n")
+    i = H.parse(str(p))
+    assert i.status == 0 and i.variables == 4 and i.less == 2 and i.greater == 4 and i.n_binary == 4
+    q = tmp_path / "quad.lp"  # lib/test/solve.cpp:236-246
+    q.write_text("minimize\n-5a + [ 2a * b + 3c * d ] /2 + 10b\nSubject to:\na + b >= 0\n"
+                 "b + c + d >= 0\nBinaries\na b c d\nEnd\n")
+    i = H.parse(str(q))
+    assert i.status == 0 and i.n_quadratic == 2 and i.n_objective == 2
+    bad = tmp_path / "bad.lp"
+    bad.write_text("minimise\n x\nst\n x >= 1\nend\n")
+    assert H.parse(str(bad)).status == 5  # bad_objective_function_type
+    assert H.parse(str(tmp_path / "missing.lp")).status == 1  # file_not_found
+
+
+def test_merged_constraints_merge_equal_rows(tmp_path):
+    """make_merged_constraints: <= and >= on the same left-hand side become one
+    row (lib/src/merged-constraint.cpp:63-127)."""
+    p = tmp_path / "m.lp"
+    p.write_text("minimize\n a + b + c\nst\n a + b + c >= 1\n a + b + c <= 2\n a + b = 1\n"
+                 "binary\n a b c\nend\n")
+    inst = H.merged(str(p))
+    assert inst.m == 2 and inst.n == 3
+    rows = {(int(inst.cmin[k]), int(inst.cmax[k])) for k in range(inst.m)}
+    assert rows == {(1, 2), (1, 1)}

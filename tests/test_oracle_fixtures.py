@@ -1,0 +1,97 @@
+"""CPU: pins the oracle (CPU restatement of the path) against the reference's
+own end-to-end expectations on its fixture files: `solve()` reaches
+`success` with a point that satisfies every constraint
+(lib/test/solve.cpp: status == success, is_valid_solution), and the two sort
+modes agree bit for bit wherever a row never has two equal reduced costs."""
+import os
+
+import numpy as np
+import pytest
+
+from baryonyx_amd import host_ffi as H
+from baryonyx_amd import synth
+from helpers import bits_equal, is_feasible, objective
+
+LP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lp")
+
+# (fixture, the solver_parameters its reference test sets -- lib/test/solve.cpp --
+# after context_set_solver_parameters' range checks: a kappa triple with
+# kappa_max > 1 is ignored, `limit = -1` means no sweep limit (capped here))
+CAP = 200000
+FIXTURES = [
+    ("assignment_problem_1.lp", dict()),                                   # :292-303
+    ("assignment_problem_2.lp", dict()),
+    ("assignment_problem_3.lp", dict()),
+    ("negative-coeff.lp", dict(limit=50, w=2.5)),                          # :337-351
+    ("negative-coeff2.lp", dict()),                                        # :353-369
+    ("negative-coeff3.lp", dict(limit=10000, w=500.0)),                    # :371-386
+    ("negative-coeff4.lp", dict(limit=50, w=2.5)),                         # :388-402
+    ("8_queens_puzzle.lp", dict(limit=CAP, theta=0.5, delta=0.02, alpha=1.0, w=40.0)),  # :431-474
+    ("flat30-7.lp", dict(limit=CAP, delta=0.001, kappa_min=0.3, kappa_step=1e-10,
+                         kappa_max=1.0, order=1, w=0.0)),                  # :531-549
+    ("uf50-0448.lp", dict(limit=CAP, theta=0.5, delta=1.0, kappa_min=0.1, kappa_step=1e-17,
+                          kappa_max=1.0, alpha=2.0, w=60.0, order=2)),     # :551-572
+    ("aim-50-1_6-yes1-2.lp", dict(limit=CAP, theta=0.6, delta=0.01, alpha=1.0, w=20.0)),  # :574-593
+    ("bound.lp", dict()),
+]
+
+
+@pytest.mark.parametrize("name,params", FIXTURES, ids=[f[0] for f in FIXTURES])
+@pytest.mark.parametrize("sort_mode", [0, 1], ids=["std_sort", "canonical"])
+def test_solve_reaches_a_valid_solution(oracle, name, params, sort_mode):
+    inst = H.merged(os.path.join(LP, name))
+    kw = dict(seed=123456789, limit=1000, w=50.0, sort_mode=sort_mode)
+    kw.update(params)
+    p = oracle.default_params(**kw)
+    res, xw = oracle.solve(inst, 1, p)
+    assert res.status == 0, f"{name}: status {res.status}, remaining {res.remaining_constraints}"
+    assert is_feasible(inst, xw)
+    assert res.value == objective(inst, xw)
+
+
+def test_sort_modes_identical_without_ties(oracle):
+    """On distinct real costs no row ever holds two equal reduced costs, the
+    shuffle draws nothing, and any correct sort gives the same result: the
+    canonical tie rule IS the reference behaviour there."""
+    inst = synth.make_scp(80, 500, 0.05, "real", 3)
+    a = oracle.Solver(inst, float_type=1, sort_mode=0, seed=5)
+    b = oracle.Solver(inst, float_type=1, sort_mode=1, seed=5)
+    delta = a.compute_delta(0.5)
+    for s in (a, b):
+        s.set_x(np.zeros(s.nwords, np.uint64))
+        s.order_init(0)
+    kappa = 0.0
+    for it in range(15):
+        ra = a.sweep(kappa, delta, 0.5, is_push=(it == 7), obj_amp=5.0 if it == 7 else 0.0)
+        rb = b.sweep(kappa, delta, 0.5, is_push=(it == 7), obj_amp=5.0 if it == 7 else 0.0)
+        assert ra == rb
+        assert np.array_equal(a.get_x(), b.get_x())
+        assert bits_equal(a.get_pi(), b.get_pi()) and bits_equal(a.get_P(), b.get_P())
+        assert a.rng == b.rng == 5  # the engine was never advanced
+        kappa += 0.03
+    assert a.tie_rows == 0 and b.tie_rows == 0
+
+
+def test_integer_costs_do_tie_and_consume_the_engine(oracle):
+    inst = synth.make_scp(80, 500, 0.05, "int", 3)
+    s = oracle.Solver(inst, float_type=1, sort_mode=1, seed=5)
+    s.set_x(np.zeros(s.nwords, np.uint64))
+    s.order_init(0)
+    s.sweep(0.0, s.compute_delta(0.5), 0.5)
+    assert s.tie_rows > 0 and s.rng != 5
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: synth.config_c1("int"),
+    lambda: synth.make_spp(40, 300, 0.06, "int", 17),
+    lambda: synth.make_pm1(50, 250, 0.06, "int", 19),
+    lambda: synth.make_z(40, 200, 0.05, "int", 5),
+])
+def test_synthetic_families_solve(oracle, maker):
+    inst = maker()
+    p = oracle.default_params(seed=7, limit=3000, w=50.0, init_policy_random=0.0, sort_mode=1)
+    res, xw = oracle.solve(inst, 1, p)
+    if res.status == 0:
+        assert is_feasible(inst, xw) and res.value == objective(inst, xw)
+    else:  # the heuristic may stop on its limits; it must say so
+        assert res.status in (4, 5) and res.remaining_constraints > 0
