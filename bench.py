@@ -107,9 +107,22 @@ def cpu_run(inst, params, float_type, seconds, nthreads):
     return sum(totals) / dt, sum(totals), dt
 
 
-def cpu_baseline(inst, params, float_type, seconds, threads):
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by
+    the cgroup CPU quota (the GPU boxes expose 256 logical CPUs but run the job
+    under a 16-CPU quota; oversubscribing it only measures the throttle)."""
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    nthreads = threads if threads > 0 else ncpu
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = min(ncpu, max(1, int(float(quota) / float(period) + 0.5)))
+    except OSError:
+        pass
+    return ncpu
+
+
+def cpu_baseline(inst, params, float_type, seconds, threads):
+    nthreads = threads if threads > 0 else usable_cores()
     one, n1, t1 = cpu_run(inst, params, float_type, seconds * 0.3, 1)
     allc, na, ta = cpu_run(inst, params, float_type, seconds * 0.7, nthreads)
     return {
