@@ -221,26 +221,68 @@ key_value(unsigned long long k, bool maximize)
     return (Float)__longlong_as_double((long long)k);
 }
 
+// Lane exchange inside a row of 16 lanes with DPP (no LDS round trip):
+// 0xB1 quad_perm(1,0,3,2), 0x4E quad_perm(2,3,0,1), 0x141 row_half_mirror,
+// 0x140 row_mirror.  After those four steps of an idempotent reduction every
+// lane of a row holds the row's result; rows are combined with two
+// ds_bpermute steps (xor 16, xor 32).
+template<int CTRL>
+__device__ inline unsigned long long
+dpp_u64(unsigned long long v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+#define BXH_WAVE_REDUCE(V, OP)                                                 \
+    do {                                                                       \
+        unsigned long long t_;                                                 \
+        t_ = dpp_u64<0xB1>(V);                                                 \
+        V = OP(t_, V);                                                         \
+        t_ = dpp_u64<0x4E>(V);                                                 \
+        V = OP(t_, V);                                                         \
+        t_ = dpp_u64<0x141>(V);                                                \
+        V = OP(t_, V);                                                         \
+        t_ = dpp_u64<0x140>(V);                                                \
+        V = OP(t_, V);                                                         \
+        t_ = __shfl_xor(V, 16, 64);                                            \
+        V = OP(t_, V);                                                         \
+        t_ = __shfl_xor(V, 32, 64);                                            \
+        V = OP(t_, V);                                                         \
+    } while (0)
+
+__device__ inline unsigned long long
+umin64(unsigned long long a, unsigned long long b)
+{
+    return a < b ? a : b;
+}
+__device__ inline unsigned long long
+umax64(unsigned long long a, unsigned long long b)
+{
+    return a > b ? a : b;
+}
+
 __device__ inline unsigned long long
 wave_min_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long t = __shfl_xor(v, o, 64);
-        v = t < v ? t : v;
-    }
+    BXH_WAVE_REDUCE(v, umin64);
     return v;
 }
 
 __device__ inline unsigned long long
 wave_max_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long t = __shfl_xor(v, o, 64);
-        v = t > v ? t : v;
-    }
+    BXH_WAVE_REDUCE(v, umax64);
     return v;
+}
+
+__device__ inline unsigned long long
+bcast_first_u64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // Open-addressing insert of a non-zero key; returns true when the key was
@@ -543,6 +585,7 @@ enum
     MS_BMAX = 7,
     MS_BNEG = 12,
     MS_RBYTES = 14, // double (8 bytes)
+    MS_RNG = 13,   // engine state after a sort-path row (all threads re-read it)
     MS_FAST = 4,   // 1: the row was resolved without sorting
     MS_SELMODE = 5, // 0: none up, 1: all up, 2: up iff key <= threshold
     MS_D = 8,      // Float d (8 bytes reserved)
@@ -943,8 +986,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         misc_s[MS_PICH] = 0;
         if (a.order == 2)
             rng.shuffle(vlist, (unsigned)nrows);
+        misc_s[MS_RNG] = (int)rng.s;
     }
     __syncthreads();
+    rng.s = (unsigned)misc_s[MS_RNG];
 
     const int l8 = tid & 7;
     Prof prof;
@@ -1192,6 +1237,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // keys next to the class borders.  Anything else (a tie, which needs
         // the shuffle and its RNG draws, or an interior rank) takes the sort.
         bool fast = false;
+        int f_mode = 0, f_nN = 0, f_nZ = 0;
+        unsigned long long f_thr = 0ull;
+        Float f_d = 0, f_newpi = 0;
+        bool f_pich = false;
         unsigned long long mykey[2] = { 0ull, 0ull };
         if (r <= 2 * T && r >= 2) {
             const unsigned long long K0 = order_key<Float>((Float)0, maximize);
@@ -1226,16 +1275,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 if (isS)
                     mnS = k < mnS ? k : mnS;
             }
-            // wave reductions (two smallest: merge of sorted pairs)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long b1 = __shfl_xor(mn1, o, 64);
-                const unsigned long long b2 = __shfl_xor(mn2, o, 64);
-                const unsigned long long lo1 = b1 < mn1 ? b1 : mn1;
-                const unsigned long long hi1 = b1 < mn1 ? mn1 : b1;
-                const unsigned long long lo2 = b2 < mn2 ? b2 : mn2;
-                mn1 = lo1;
-                mn2 = hi1 < lo2 ? hi1 : lo2;
+            // wave reductions; the second smallest is the minimum of what is
+            // left once the wave's smallest key is known (keys are distinct
+            // unless the row has a tie, which takes the sort path anyway)
+            {
+                const unsigned long long own1 = mn1, own2 = mn2;
+                mn1 = wave_min_u64(mn1);
+                mn2 = own1 == mn1 ? own2 : own1;
+                mn2 = wave_min_u64(mn2);
             }
             mx1 = wave_max_u64(mx1);
             mxN = wave_max_u64(mxN);
@@ -1257,26 +1304,42 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             BXH_STAMP(8);
             __syncthreads();
             BXH_STAMP(9);
-            if (tid == 0) {
+            // Every wave merges the per-wave partials with its first lanes and
+            // then runs the same, wave-uniform selection logic: no second
+            // barrier, no broadcast through LDS.  All threads keep identical
+            // copies of the engine state (re-read after a sort-path row).
+            {
                 const int nw = T >> 6;
-                const unsigned long long* part = part_s;
-                unsigned long long g1 = ~0ull, g2 = ~0ull, gx = 0ull, gxN = 0ull, gnS = ~0ull;
-                int nN = 0, nZ = 0;
-                bool anytie = false;
-                for (int w = 0; w < nw; ++w) {
-                    const unsigned long long a1 = part[w * 8], a2 = part[w * 8 + 1];
-                    const unsigned long long lo1 = a1 < g1 ? a1 : g1;
-                    const unsigned long long hi1 = a1 < g1 ? g1 : a1;
-                    const unsigned long long lo2 = a2 < g2 ? a2 : g2;
+                const int lane = tid & 63;
+                const bool lv = lane < nw;
+                const unsigned long long* part = part_s + (lv ? lane : 0) * 8;
+                unsigned long long g1 = lv ? part[0] : ~0ull, g2 = lv ? part[1] : ~0ull;
+                unsigned long long gx = lv ? part[2] : 0ull, gxN = lv ? part[3] : 0ull;
+                unsigned long long gnS = lv ? part[4] : ~0ull;
+                unsigned long long cnt = lv ? part[5] : 0ull; // counts add without carry
+                unsigned long long tflag = lv ? part[6] : 0ull;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { // nw <= 16
+                    const unsigned long long b1 = __shfl_xor(g1, o, 64);
+                    const unsigned long long b2 = __shfl_xor(g2, o, 64);
+                    const unsigned long long lo1 = umin64(b1, g1), hi1 = umax64(b1, g1);
+                    g2 = umin64(hi1, umin64(b2, g2));
                     g1 = lo1;
-                    g2 = hi1 < lo2 ? hi1 : lo2;
-                    gx = part[w * 8 + 2] > gx ? part[w * 8 + 2] : gx;
-                    gxN = part[w * 8 + 3] > gxN ? part[w * 8 + 3] : gxN;
-                    gnS = part[w * 8 + 4] < gnS ? part[w * 8 + 4] : gnS;
-                    nN += (int)(part[w * 8 + 5] >> 32);
-                    nZ += (int)(part[w * 8 + 5] & 0xffffffffu);
-                    anytie = anytie || part[w * 8 + 6] != 0ull;
+                    gx = umax64(gx, __shfl_xor(gx, o, 64));
+                    gxN = umax64(gxN, __shfl_xor(gxN, o, 64));
+                    gnS = umin64(gnS, __shfl_xor(gnS, o, 64));
+                    cnt += __shfl_xor(cnt, o, 64);
+                    tflag |= __shfl_xor(tflag, o, 64);
                 }
+                g1 = bcast_first_u64(g1);
+                g2 = bcast_first_u64(g2);
+                gx = bcast_first_u64(gx);
+                gxN = bcast_first_u64(gxN);
+                gnS = bcast_first_u64(gnS);
+                cnt = bcast_first_u64(cnt);
+                tflag = bcast_first_u64(tflag);
+                const int nN = (int)(cnt >> 32), nZ = (int)(cnt & 0xffffffffu);
+                const bool anytie = tflag != 0ull;
                 bool ok = !anytie;
                 const unsigned saved_rng = rng.s;
                 int sel = 0;
@@ -1349,46 +1412,49 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 if (!ok) {
                     rng.s = saved_rng; // the sort path redoes the scan
                 } else {
-                    alg_bytes += *(const double*)(misc_s + MS_RBYTES);
                     const Float one = 1, two = 2;
                     const Float middle = (two + one) / two;
                     Float d = delta;
                     const Float v_sel = key_value<Float>(k_sel, maximize);
                     if (sel < 0) {
                         d += kfac * (v_sel / two);
-                        misc_s[MS_SELMODE] = 0;
+                        f_mode = 0;
                     } else if (sel + 1 >= r) {
                         d += kfac * (v_sel * middle);
-                        misc_s[MS_SELMODE] = 1;
+                        f_mode = 1;
                     } else {
                         const Float v_sel1 = key_value<Float>(k_sel1, maximize);
                         const Float old_pi = pi_s[k];
                         const Float new_pi = old_pi + ((v_sel + v_sel1) / two);
-                        pi_s[k] = new_pi;
                         d += kfac * (v_sel1 - v_sel);
-                        if (signbit(old_pi) != signbit(new_pi))
-                            misc_s[MS_PICH] = 1;
-                        misc_s[MS_SELMODE] = 2;
-                        *(unsigned long long*)(misc_s + MS_THR) = k_sel;
+                        f_mode = 2;
+                        f_thr = k_sel;
+                        f_newpi = new_pi;
+                        f_pich = signbit(old_pi) != signbit(new_pi);
                     }
-                    *d_s = d;
-                    misc_s[MS_FAST] = 1;
-                    // classes by sorted position, for the next stale read
-                    misc_s[MS_SEL] = nN;
-                    misc_s[MS_CNT] = nZ;
+                    f_d = d;
+                    f_nN = nN;
+                    f_nZ = nZ;
+                    fast = true;
                 }
             }
             BXH_STAMP(10);
-            __syncthreads();
-            fast = misc_s[MS_FAST] != 0;
         }
         if (fast) {
             BXH_STAMP(1);
             // ---- affect without the sorted order ------------------------------
-            const int mode = misc_s[MS_SELMODE];
-            const unsigned long long thr = *(const unsigned long long*)(misc_s + MS_THR);
-            const Float d = *d_s;
-            const int nN = misc_s[MS_SEL], nZ = misc_s[MS_CNT];
+            const int mode = f_mode;
+            const unsigned long long thr = f_thr;
+            const Float d = f_d;
+            const int nN = f_nN, nZ = f_nZ;
+            if (tid == 0) {
+                alg_bytes += *(const double*)(misc_s + MS_RBYTES);
+                if (mode == 2) {
+                    pi_s[k] = f_newpi;
+                    if (f_pich)
+                        misc_s[MS_PICH] = 1;
+                }
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int idx = tid + s2 * T;
@@ -1503,8 +1569,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             }
             misc_s[MS_SEL] = sel;
             *d_s = d;
+            misc_s[MS_RNG] = (int)rng.s;
         }
         __syncthreads();
+        rng.s = (unsigned)misc_s[MS_RNG]; // every thread tracks the engine
         BXH_STAMP(5);
 
         // ---- affect: x bits and P of the row, by sorted position -----------
