@@ -78,7 +78,8 @@ struct bxh_handle_s
     size_t lds_bytes_init = 0; // order_init kernel
     int version = 1;           // 1: lane-per-column walk, 2: staged column loads
     int nb = 0;                // v2: 16-entry pieces per staged column
-    int lr = 2;                // v2: 8-column load rounds per wave chunk
+    int groups = 1;            // v2: workgroups (column owners) per instance
+    int romax = 0;             // longest per-owner part of a row
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -88,6 +89,11 @@ struct bxh_handle_s
     DevBuf<int2> row_cs;
     DevBuf<signed char> fac_csr;
     DevBuf<unsigned short> col_row16;
+    DevBuf<int> sub_ptr, sub_e;      // per-owner row parts (groups > 1)
+    DevBuf<unsigned> ownmask;        // [groups][2*nwords] x bits of each owner
+    DevBuf<int> vwork, vpart;        // [batch][groups][m]
+    DevBuf<unsigned long long> xbuf; // [batch][2][rmax] reduced-cost exchange
+    DevBuf<unsigned> cnt;            // [2*batch] arrival counters + [1] error flag
     DevBuf<unsigned char> cost; // Float[n]
     DevBuf<double> row_bytes;   // [m]
     // host copies needed for state import/export and accounting
@@ -221,15 +227,15 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
     }
     HIP_TRY(hipEventRecord(h->events[h->events_used].first, h->stream));
 #define BXH_LAUNCH(K)                                                          \
-    hipLaunchKernelGGL(K, dim3(h->batch), dim3(h->threads), h->lds_bytes,      \
-                       h->stream, h->dp, h->ds, a)
+    hipLaunchKernelGGL(K, dim3(h->batch * h->groups), dim3(h->threads),        \
+                       h->lds_bytes, h->stream, h->dp, h->ds, a)
     if (h->version == 2) {
 #define BXH_V2(PM, NPV)                                                        \
     do {                                                                       \
-        if (h->lr == 1)                                                        \
-            BXH_LAUNCH((bxh::sweep_kernel_v2<Float, PM, NPV, 1>));             \
+        if (h->groups > 1)                                                     \
+            BXH_LAUNCH((bxh::sweep_kernel_v2<Float, PM, NPV, true>));          \
         else                                                                   \
-            BXH_LAUNCH((bxh::sweep_kernel_v2<Float, PM, NPV, 2>));             \
+            BXH_LAUNCH((bxh::sweep_kernel_v2<Float, PM, NPV, false>));         \
     } while (0)
         if (pm1) {
             if (h->nb == 4)
@@ -351,36 +357,90 @@ bxh_create(const bxh_problem* pb,
         col_ptr[j + 1] += col_ptr[j];
     h->rmax = rmax;
 
-    // Device CSC: every column padded to a multiple of 16 entries (128 bytes of
-    // fp64 P), so a column is a whole number of cache-line pieces.  Padding
-    // slots hold row index m (pi_s[m] == 0 on the device) and P == 0 for ever.
+    int cmax = 0;
+    for (int j = 0; j != n; ++j)
+        cmax = std::max(cmax, col_ptr[j + 1] - col_ptr[j]);
+
+    // ---- kernel choice: staged pipeline (v2) where the instance fits it, and
+    // then how many workgroups (column owners) cooperate on one instance: all
+    // of them must be resident together, one per CU ----------------------
+    const char* force_v1 = std::getenv("BXH_FORCE_V1");
+    const bool v2_ok = cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
+    int groups = 1;
+    if (v2_ok) {
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        while (groups < 4 && batch * groups * 2 <= cus && rmax / (groups * 2) >= 16)
+            groups *= 2;
+        if (const char* eg = std::getenv("BXH_GROUPS")) {
+            const int g = std::atoi(eg);
+            if ((g == 1 || g == 2 || g == 4) && batch * g <= cus)
+                groups = g;
+        }
+    }
+    h->groups = groups;
+
+    // Device CSC, per owner (column j belongs to workgroup j % groups): every
+    // column padded to a multiple of 16 entries (128 bytes of fp64 P), so a
+    // column is a whole number of cache-line pieces.  Padding slots hold row
+    // index m (pi_s[m] == 0 on the device) and P == 0 for ever.
     std::vector<int> col_start(static_cast<size_t>(n)), col_len(static_cast<size_t>(n));
-    long long nnzp_ll = 0;
+    std::vector<long long> gsize(static_cast<size_t>(groups), 0);
     for (int j = 0; j != n; ++j) {
-        col_start[j] = static_cast<int>(nnzp_ll);
+        const int g = j % groups;
+        col_start[j] = static_cast<int>(gsize[g]);
         col_len[j] = col_ptr[j + 1] - col_ptr[j];
-        nnzp_ll += std::max(16, (col_len[j] + 15) & ~15);
-        if (nnzp_ll > 0x7fffffffLL)
+        gsize[g] += std::max(16, (col_len[j] + 15) & ~15);
+        if (gsize[g] * groups > 0x7fffffffLL)
             return fail(BXH_ERR_UNSUPPORTED, "more than 2^31-1 padded elements");
     }
-    const int nnzp = static_cast<int>(nnzp_ll);
-    h->nnzp = nnzp;
-    std::vector<int> col_row(static_cast<size_t>(nnzp), m), row_pos(static_cast<size_t>(nnz));
+    const int nnzp = static_cast<int>(*std::max_element(gsize.begin(), gsize.end()));
+    h->nnzp = nnzp; // stride of one owner's slice
+    std::vector<int> col_row(static_cast<size_t>(nnzp) * groups, m), row_pos(static_cast<size_t>(nnz));
     std::vector<signed char> fac_csr(pm1 ? nnz : 0);
     {
         std::vector<int> fill(col_start);
         for (int k = 0; k != m; ++k)
             for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e) {
-                const int q = fill[pb->col[e]]++;
-                col_row[q] = k;
+                const int j = pb->col[e];
+                const int q = fill[j]++;
+                const size_t at = static_cast<size_t>(j % groups) * nnzp + q;
+                col_row[at] = k;
                 row_pos[e] = q;
                 if (pm1) {
                     fac_csr[e] = static_cast<signed char>(pb->factor[e]);
                     if (pb->factor[e] < 0)
-                        col_row[q] |= 0x40000000;
+                        col_row[at] |= 0x40000000;
                 }
             }
     }
+    // per-owner parts of every row (element ids in row order) and x bit masks
+    std::vector<int> sub_ptr, sub_e;
+    std::vector<unsigned> ownmask;
+    int romax = rmax;
+    if (groups > 1) {
+        romax = 0;
+        sub_ptr.assign(static_cast<size_t>(groups) * (m + 1), 0);
+        sub_e.reserve(static_cast<size_t>(nnz));
+        for (int g = 0; g != groups; ++g)
+            for (int k = 0; k != m; ++k) {
+                sub_ptr[static_cast<size_t>(g) * (m + 1) + k] = static_cast<int>(sub_e.size());
+                for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e)
+                    if (pb->col[e] % groups == g)
+                        sub_e.push_back(e);
+                const int len = static_cast<int>(sub_e.size()) -
+                                sub_ptr[static_cast<size_t>(g) * (m + 1) + k];
+                romax = std::max(romax, len);
+                if (k == m - 1)
+                    sub_ptr[static_cast<size_t>(g) * (m + 1) + m] = static_cast<int>(sub_e.size());
+            }
+        ownmask.assign(static_cast<size_t>(groups) * 2 * h->nwords, 0u);
+        for (int j = 0; j != n; ++j)
+            ownmask[static_cast<size_t>(j % groups) * 2 * h->nwords + (j >> 5)] |= 1u << (j & 31);
+    }
+    h->romax = romax;
 
     // ---- bounds as each Solver constructor clamps them --------------------
     std::vector<int> bmin(m), bmax(m), bneg(m, 0);
@@ -432,9 +492,6 @@ bxh_create(const bxh_problem* pb,
     }
 
     // ---- launch geometry ----------------------------------------------------
-    int cmax = 0;
-    for (int j = 0; j != n; ++j)
-        cmax = std::max(cmax, col_len[j]);
     std::vector<int2> row_cs(static_cast<size_t>(nnz));
     for (int e = 0; e != nnz; ++e) {
         const int j = pb->col[e];
@@ -453,32 +510,24 @@ bxh_create(const bxh_problem* pb,
     h->version = 1;
     h->lds_bytes = static_cast<size_t>(lp.total);
     h->threads = std::min(1024, std::max(64, bxh::next_pow2(rmax)));
-    const char* force_v1 = std::getenv("BXH_FORCE_V1");
-    // v2 stages 15-bit row indices: m (the padding index) must fit
-    if (cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1')) {
+    if (v2_ok) {
         const int np = cmax <= 64 ? 4 : (cmax <= 96 ? 6 : 8);
-        // 8 staging slots per wave with 16 waves (the more waves, the better
-        // the dependent add chains of the column sums overlap), else 16
-        // slots per wave with fewer waves, as LDS allows
-        const char* force_lr = std::getenv("BXH_FORCE_LR");
-        // (the 16-wave variant needs <= 128 VGPRs and spills: measured slower)
-        const int cand[4][2] = { { 512, 2 }, { 256, 2 }, { 128, 2 }, { 1024, 1 } };
-        for (int c = 0; c != 4; ++c) {
-            const int t = cand[c][0], lr = cand[c][1];
-            if (force_lr && force_lr[0] == '2' && lr == 1)
-                continue;
-            const bxh::LdsPlan2 lp2 = bxh::lds_plan2(
-              m, h->nwords, rmax, static_cast<int>(h->fsize), (t / 64) * 8 * lr, np);
+        // 16 staging slots per wave; as many waves (up to 8) as LDS allows
+        for (int t = 512; t >= 128; t >>= 1) {
+            const bxh::LdsPlan2 lp2 = bxh::lds_plan2(m, h->nwords, rmax, romax,
+                                                     static_cast<int>(h->fsize),
+                                                     (t / 64) * 16, np, groups > 1);
             if (lp2.total <= lds_limit) {
                 h->version = 2;
                 h->nb = np;
-                h->lr = lr;
                 h->threads = t;
                 h->lds_bytes = static_cast<size_t>(lp2.total);
                 break;
             }
         }
     }
+    if (h->version != 2 && groups > 1)
+        return fail(BXH_ERR_UNSUPPORTED, "instance does not fit the staged kernel's LDS plan");
 
     HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
@@ -502,6 +551,9 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->bmax.upload(bmax));
     HIP_TRY(h->bneg.upload(bneg));
     HIP_TRY(h->fac_csr.upload(fac_csr));
+    HIP_TRY(h->sub_ptr.upload(sub_ptr));
+    HIP_TRY(h->sub_e.upload(sub_e));
+    HIP_TRY(h->ownmask.upload(ownmask));
     {
         std::vector<unsigned char> c;
         if (float_type == BXH_FLOAT)
@@ -522,19 +574,25 @@ bxh_create(const bxh_problem* pb,
     }
 
     const size_t B = static_cast<size_t>(batch);
-    HIP_TRY(h->P.alloc(B * nnzp * h->fsize));
+    const size_t GG = static_cast<size_t>(groups);
+    HIP_TRY(h->P.alloc(B * GG * nnzp * h->fsize));
+    HIP_TRY(h->vwork.alloc(B * GG * m));
+    HIP_TRY(h->vpart.alloc(B * GG * m));
+    HIP_TRY(h->xbuf.alloc(B * 2 * rmax));
+    HIP_TRY(h->cnt.alloc(2 * B + 1));
+    HIP_TRY(hipMemset(h->cnt.p, 0, (2 * B + 1) * sizeof(unsigned)));
     HIP_TRY(h->pi.alloc(B * m * h->fsize));
     HIP_TRY(h->rstale.alloc(B * (rmax + 1) * h->fsize));
     HIP_TRY(h->x.alloc(B * 2 * h->nwords));
     HIP_TRY(h->vlist.alloc(B * m));
     HIP_TRY(h->vcount.alloc(B));
-    HIP_TRY(h->vflag.alloc(B * m));
+    HIP_TRY(h->vflag.alloc(B * GG * m));
     HIP_TRY(h->status.alloc(B));
     HIP_TRY(h->prof.alloc(B * 16));
     HIP_TRY(hipMemset(h->prof.p, 0, B * 16 * sizeof(unsigned long long)));
     HIP_TRY(h->kappa.alloc(B));
     HIP_TRY(h->active.alloc(B));
-    HIP_TRY(hipMemset(h->P.p, 0, B * nnzp * h->fsize));
+    HIP_TRY(hipMemset(h->P.p, 0, B * GG * nnzp * h->fsize));
     HIP_TRY(hipMemset(h->pi.p, 0, B * m * h->fsize));
     HIP_TRY(hipMemset(h->rstale.p, 0, B * (rmax + 1) * h->fsize));
     HIP_TRY(hipMemset(h->x.p, 0, B * 2 * h->nwords * sizeof(unsigned)));
@@ -574,30 +632,30 @@ bxh_create(const bxh_problem* pb,
             BXH_SET_LDS((bxh::sweep_kernel<double, true>));
             BXH_SET_LDS((bxh::order_init_kernel<float>));
             BXH_SET_LDS((bxh::order_init_kernel<double>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, 2>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, 1>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, 2>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, true>));
         }
 #undef BXH_SET_LDS
     }
@@ -607,6 +665,11 @@ bxh_create(const bxh_problem* pb,
     dp.n = n;
     dp.nnz = nnz;
     dp.nnzp = nnzp;
+    dp.groups = groups;
+    dp.romax = romax;
+    dp.sub_ptr = h->sub_ptr.p;
+    dp.sub_e = h->sub_e.p;
+    dp.ownmask = h->ownmask.p;
     dp.rmax = rmax;
     dp.cmax = cmax;
     dp.nwords = h->nwords;
@@ -637,6 +700,10 @@ bxh_create(const bxh_problem* pb,
     ds.vflag = h->vflag.p;
     ds.status = h->status.p;
     ds.prof = h->prof.p;
+    ds.vwork = h->vwork.p;
+    ds.vpart = h->vpart.p;
+    ds.xbuf = h->xbuf.p;
+    ds.cnt = h->cnt.p;
 
     *out = guard.release();
     return BXH_OK;
@@ -744,11 +811,11 @@ bxh_set_P(bxh_handle h, int inst, const double* v)
 {
     if (int rc = check_inst(h, inst))
         return rc;
-    std::vector<double> csc(static_cast<size_t>(h->nnzp), 0.0); // padding stays 0
+    const size_t slice = static_cast<size_t>(h->nnzp), all = slice * h->groups;
+    std::vector<double> csc(all, 0.0); // padding stays 0
     for (int e = 0; e != h->nnz; ++e)
-        csc[h->h_row_pos[e]] = v[e];
-    return set_vec(
-      h, h->P.p + static_cast<size_t>(inst) * h->nnzp * h->fsize, csc.data(), h->nnzp);
+        csc[static_cast<size_t>(h->h_row_col[e] % h->groups) * slice + h->h_row_pos[e]] = v[e];
+    return set_vec(h, h->P.p + static_cast<size_t>(inst) * all * h->fsize, csc.data(), all);
 }
 
 int
@@ -756,14 +823,12 @@ bxh_get_P(bxh_handle h, int inst, double* v)
 {
     if (int rc = check_inst(h, inst))
         return rc;
-    std::vector<double> csc(static_cast<size_t>(h->nnzp));
-    if (int rc = get_vec(h,
-                         h->P.p + static_cast<size_t>(inst) * h->nnzp * h->fsize,
-                         csc.data(),
-                         h->nnzp))
+    const size_t slice = static_cast<size_t>(h->nnzp), all = slice * h->groups;
+    std::vector<double> csc(all);
+    if (int rc = get_vec(h, h->P.p + static_cast<size_t>(inst) * all * h->fsize, csc.data(), all))
         return rc;
     for (int e = 0; e != h->nnz; ++e)
-        v[e] = csc[h->h_row_pos[e]];
+        v[e] = csc[static_cast<size_t>(h->h_row_col[e] % h->groups) * slice + h->h_row_pos[e]];
     return BXH_OK;
 }
 
@@ -795,9 +860,9 @@ bxh_reset(bxh_handle h, int inst)
     if (int rc = check_inst(h, inst))
         return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemset(h->P.p + static_cast<size_t>(inst) * h->nnzp * h->fsize,
+    HIP_TRY(hipMemset(h->P.p + static_cast<size_t>(inst) * h->nnzp * h->groups * h->fsize,
                       0,
-                      static_cast<size_t>(h->nnzp) * h->fsize));
+                      static_cast<size_t>(h->nnzp) * h->groups * h->fsize));
     HIP_TRY(hipMemset(h->pi.p + static_cast<size_t>(inst) * h->m * h->fsize,
                       0,
                       static_cast<size_t>(h->m) * h->fsize));
@@ -901,6 +966,9 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
                                h->stream));
         s.active = h->active.p;
     }
+    if (h->groups > 1) // arrival counters of the cooperating workgroups
+        HIP_TRY(hipMemsetAsync(h->cnt.p, 0, 2 * static_cast<size_t>(h->batch) * sizeof(unsigned),
+                               h->stream));
     return h->float_type == BXH_FLOAT ? launch_sweep<float>(h, s)
                                       : launch_sweep<double>(h, s);
 }
@@ -919,6 +987,14 @@ bxh_status_sync(bxh_handle h, bxh_status* out)
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rc = drain_events(h))
         return rc;
+    if (h->groups > 1) {
+        unsigned err = 0;
+        HIP_TRY(hipMemcpy(&err, h->cnt.p + 2 * h->batch, sizeof err, hipMemcpyDeviceToHost));
+        if (err)
+            return fail(BXH_ERR_DEVICE,
+                        "a workgroup timed out waiting for its partners (the "
+                        "cooperating workgroups were not all resident)");
+    }
     if (out) {
         static_assert(sizeof(bxh_status) == sizeof(bxh::DevStatus), "ABI");
         std::memcpy(out, h->h_status, static_cast<size_t>(h->batch) * sizeof(bxh_status));

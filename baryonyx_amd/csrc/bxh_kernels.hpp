@@ -26,7 +26,9 @@ namespace bxh {
 struct DevProblem
 {
     int m, n, nnz, rmax, nwords;
-    int nnzp;     // CSC slots per instance: every column padded to 16 entries
+    int nnzp;     // CSC slots of one owner's slice (columns padded to 16 entries)
+    int groups;   // workgroups (column owners, column j -> j % groups) per instance
+    int romax;    // longest per-owner part of a row
     int cmax;     // longest column (real entries)
     int kind;     // bxh_kind
     int maximize; // 0 / 1
@@ -41,6 +43,9 @@ struct DevProblem
                                //         (pi_s[m] == 0, P == 0 there for ever)
     const unsigned short* col_row16; // [nnzp] the same in 16 bits (bit 15 = -1),
                                //         only when m < 32768 (v2 kernel)
+    const int* sub_ptr;        // [groups][m+1] per-owner part of row k in sub_e
+    const int* sub_e;          // CSR element ids, row order, owner after owner
+    const unsigned* ownmask;   // [groups][2*nwords] x bits of each owner
     const signed char* fac_csr; // [nnz]  coefficient of CSR element (101 kinds)
     const int* bmin;           // [m] clamped as the Solver constructor does
     const int* bmax;           // [m]
@@ -71,6 +76,10 @@ struct DevState
     signed char* vflag;  // [batch][m] scratch
     DevStatus* status;   // [batch]
     unsigned long long* prof; // [batch][16] phase ticks (profiling build only)
+    int* vwork;          // [batch][groups][m] private copy of the row list
+    int* vpart;          // [batch][groups][m] per-owner row activities
+    unsigned long long* xbuf; // [batch][2][rmax] reduced costs of the current row
+    unsigned* cnt;       // [batch] row arrivals, [batch] sweep-end arrivals, [1] error
 };
 
 struct Prof
@@ -865,14 +874,105 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
 // summation order of compute_reduced_costs
 // (itm-solver-inequalities-01.cpp:173-188) is untouched, so results stay
 // bit-identical.  The loads of pass p+1 are in flight while pass p is summed.
+// Wait until `*cnt >= target` (arrivals of the cooperating workgroups), one
+// polling lane, bounded: a missing partner sets the error word instead of
+// hanging the GPU.
+__device__ inline void
+wait_arrivals(unsigned* cnt, unsigned target, unsigned* err)
+{
+    long spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > 4000000L) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+// compute_violated_constraints with several column owners: every workgroup
+// adds up the row activities of its own columns, the partial sums are
+// exchanged through L2 (one arrival per workgroup), and each workgroup builds
+// the same ordered list from the totals.
+__device__ inline int
+rebuild_violated_owners(const DevProblem& pb,
+                        int grp,
+                        int ngroups,
+                        const unsigned* x_s,
+                        int* vpart_inst, // [groups][m] of this instance
+                        unsigned* cnt_end,
+                        unsigned* err_word,
+                        signed char* vflag,
+                        int* vout,
+                        int* scratch_s)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    const bool pm1 = pb.kind >= 2;
+    const int* sub_ptr = pb.sub_ptr + (size_t)grp * (pb.m + 1);
+
+    for (int k = wave; k < pb.m; k += nwaves) {
+        const int os = sub_ptr[k], oe = sub_ptr[k + 1];
+        int v = 0;
+        for (int t = os + lane; t < oe; t += 64) {
+            const int e = pb.sub_e[t];
+            const int j = pb.row_col[e];
+            const int bit = (x_s[j >> 5] >> (j & 31)) & 1u;
+            v += pm1 ? (int)pb.fac_csr[e] * bit : bit;
+        }
+        v = wave_sum(v);
+        if (lane == 0)
+            __hip_atomic_store(&vpart_inst[(size_t)grp * pb.m + k], v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(cnt_end, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wait_arrivals(cnt_end, (unsigned)ngroups, err_word);
+    }
+    __syncthreads();
+    for (int k = tid; k < pb.m; k += T) {
+        int v = 0;
+        for (int g = 0; g < ngroups; ++g)
+            v += __hip_atomic_load(&vpart_inst[(size_t)g * pb.m + k], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        vflag[k] = !(pb.bmin[k] <= v && v <= pb.bmax[k]);
+    }
+    __syncthreads();
+
+    int base = 0;
+    for (int c = 0; c < pb.m; c += T) {
+        const int k = c + tid;
+        const bool f = k < pb.m && vflag[k] != 0;
+        const unsigned long long mask = __ballot(f);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            scratch_s[wave] = __popcll(mask);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w = 0; w < nwaves; ++w) {
+            const int cw = scratch_s[w];
+            if (w < wave)
+                off += cw;
+            tot += cw;
+        }
+        if (f)
+            vout[base + off + prefix] = k;
+        base += tot;
+        __syncthreads();
+    }
+    return base;
+}
+
 struct LdsPlan2
 {
-    int off_pi, off_x, off_val, off_sp, off_cs, off_pe, off_col, off_stale,
-      off_misc, off_part, off_union, stage_i_off, total;
+    int off_pi, off_x, off_val, off_sp, off_cs, off_pe, off_col, off_spi, off_oidx,
+      off_loc, off_stale, off_misc, off_part, off_union, stage_i_off, total;
 };
 
 __host__ __device__ inline LdsPlan2
-lds_plan2(int m, int nwords, int rmax, int fsize, int slots, int np)
+lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, bool mw)
 {
     auto al = [](int v) { return (v + 15) & ~15; };
     LdsPlan2 p;
@@ -884,13 +984,24 @@ lds_plan2(int m, int nwords, int rmax, int fsize, int slots, int np)
     p.off_val = o;
     o = al(o + rmax * fsize);
     p.off_sp = o;
-    o = al(o + rmax * fsize);
+    o = al(o + romax * fsize);
     p.off_cs = o;
-    o = al(o + rmax * 8);
+    o = al(o + romax * 8);
     p.off_pe = o;
-    o = al(o + rmax * 4);
+    o = al(o + romax * 4);
     p.off_col = o;
-    o = al(o + rmax * 4);
+    o = al(o + romax * 4);
+    p.off_spi = p.off_val; // one owner: the pi sums sit in val_s until combined
+    p.off_oidx = o;
+    p.off_loc = o;
+    if (mw) { // several owners: own arrays are indexed by the owner's position
+        p.off_spi = o;
+        o = al(o + romax * fsize);
+        p.off_oidx = o;
+        o = al(o + romax * 4);
+        p.off_loc = o;
+        o = al(o + rmax * 2);
+    }
     p.off_stale = o;
     o = al(o + (rmax + 1) * fsize);
     p.off_misc = o;
@@ -909,12 +1020,31 @@ lds_plan2(int m, int nwords, int rmax, int fsize, int slots, int np)
     return p;
 }
 
-template<typename Float, bool PM1, int NP, int LR>
-__global__ __launch_bounds__(LR == 1 ? 1024 : 512) void
+// MW: several workgroups cooperate on one instance.  Column j belongs to
+// workgroup j % groups, which alone reads and writes the P entries and the x
+// bit of that column; every workgroup keeps its own copy of pi, of the row's
+// reduced costs (exchanged once per row through L2) and of the engine, and
+// takes the same selection decisions from them.
+template<typename Float, bool PM1, int NP, bool MW>
+__global__ __launch_bounds__(512) void
 sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int inst = blockIdx.x;
+    constexpr int LR = 2;
+    const int NG = MW ? pb.groups : 1;
+    int inst = blockIdx.x, grp = 0;
+    if (MW) {
+        const int b = blockIdx.x, ninst = gridDim.x / NG;
+        if ((ninst & 7) == 0) {
+            // blocks 8 apart share an XCD under round-robin dispatch: keep the
+            // partners of an instance on one L2 (speed only)
+            inst = (b & 7) + 8 * ((b >> 3) / NG);
+            grp = (b >> 3) % NG;
+        } else {
+            inst = b / NG;
+            grp = b % NG;
+        }
+    }
     if (a.active && !a.active[inst])
         return;
 
@@ -924,11 +1054,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     constexpr int SI = NP * 16 + 4; // 16-bit entries of an index slot (8-byte rows)
     typedef Float Float2 __attribute__((ext_vector_type(2)));
     const LdsPlan2 lp =
-      lds_plan2(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float), G, NP);
+      lds_plan2(pb.m, pb.nwords, pb.rmax, MW ? pb.romax : pb.rmax, (int)sizeof(Float), G, NP, MW);
     Float* pi_s = (Float*)(smem + lp.off_pi);
     unsigned* x_s = (unsigned*)(smem + lp.off_x);
     Float* val_s = (Float*)(smem + lp.off_val);
     Float* sp_s = (Float*)(smem + lp.off_sp);
+    Float* spi_s = (Float*)(smem + lp.off_spi); // == val_s with one owner
+    int* oidx_s = (int*)(smem + lp.off_oidx);   // MW: row position of own entry l
+    short* loc_s = (short*)(smem + lp.off_loc); // MW: own entry of row position, or -1
     int2* cs_s = (int2*)(smem + lp.off_cs);
     int* pe_s = (int*)(smem + lp.off_pe);
     int* col_s = (int*)(smem + lp.off_col);
@@ -952,11 +1085,17 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const bool maximize = pb.maximize != 0;
     const int kind = pb.kind;
 
-    Float* P = (Float*)st.P + (size_t)inst * pb.nnzp;
+    Float* P = (Float*)st.P + ((size_t)inst * NG + grp) * pb.nnzp;
+    const unsigned short* crow = pb.col_row16 + (size_t)grp * pb.nnzp;
+    unsigned* const cnt_row = st.cnt + inst;
+    unsigned* const cnt_end = st.cnt + gridDim.x / NG + inst;
+    unsigned* const err_word = st.cnt + 2 * (gridDim.x / NG);
     Float* pig = (Float*)st.pi + (size_t)inst * pb.m;
     unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
     Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
     int* vlist = st.vlist + (size_t)inst * pb.m;
+    // several owners: each works on a private copy of the row list
+    int* vrows = MW ? st.vwork + ((size_t)inst * NG + grp) * pb.m : vlist;
     const Float* cost = (const Float*)pb.cost;
 
     const Float kappa = (Float)a.kappa[inst];
@@ -982,10 +1121,15 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const int nrows = st.vcount[inst];
     double alg_bytes = 0.0; // thread 0 only
 
+    if (MW) {
+        for (int i = tid; i < nrows; i += T)
+            vrows[i] = vlist[i];
+        __syncthreads();
+    }
     if (tid == 0) {
         misc_s[MS_PICH] = 0;
         if (a.order == 2)
-            rng.shuffle(vlist, (unsigned)nrows);
+            rng.shuffle(vrows, (unsigned)nrows);
         misc_s[MS_RNG] = (int)rng.s;
     }
     __syncthreads();
@@ -1002,58 +1146,76 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     // row ids and extents one row ahead (three dependent global loads
     // otherwise sit at the head of every row)
     auto row_at = [&](int it_) -> int {
-        return (a.order == 1) ? vlist[nrows - 1 - it_] : vlist[it_];
+        return (a.order == 1) ? vrows[nrows - 1 - it_] : vrows[it_];
     };
     int k_next = nrows > 0 ? row_at(0) : 0;
     int rs_next = nrows > 0 ? pb.row_ptr[k_next] : 0;
     int re_next = nrows > 0 ? pb.row_ptr[k_next + 1] : 0;
+    const int* sub_ptr = MW ? pb.sub_ptr + (size_t)grp * (pb.m + 1) : nullptr;
+    int os_next = (MW && nrows > 0) ? sub_ptr[k_next] : 0;
+    int oe_next = (MW && nrows > 0) ? sub_ptr[k_next + 1] : 0;
     // the next row's descriptor (column start / padded length, CSC slot and
     // column of each element) travels in registers while this row is worked on
     int2 d_cs[2];
-    int d_pe[2], d_col[2];
-    auto fetch_desc = [&](int rs_, int r_) {
+    int d_pe[2], d_col[2], d_oidx[2];
+    auto fetch_desc = [&](int rs_, int ro_, int os_) { // own entries l < ro_
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const int idx = tid + s2 * T;
-            if (idx < r_) {
-                d_cs[s2] = pb.row_cs[rs_ + idx];
-                d_pe[s2] = pb.row_pos[rs_ + idx];
-                d_col[s2] = pb.row_col[rs_ + idx];
+            const int l = tid + s2 * T;
+            if (l < ro_) {
+                const int e = MW ? pb.sub_e[os_ + l] : rs_ + l;
+                d_cs[s2] = pb.row_cs[e];
+                d_pe[s2] = pb.row_pos[e];
+                d_col[s2] = pb.row_col[e];
+                d_oidx[s2] = e - rs_;
             }
         }
     };
     if (nrows > 0)
-        fetch_desc(rs_next, re_next - rs_next);
+        fetch_desc(rs_next, MW ? oe_next - os_next : re_next - rs_next, os_next);
 
     for (int it = 0; it < nrows; ++it) {
         const int k = k_next;
         const int rs = rs_next;
-        const int r = re_next - rs_next;
+        const int r = re_next - rs_next;              // the whole row
+        const int os = os_next;
+        const int ro = MW ? oe_next - os_next : r;    // this owner's entries
 
         // ---- row descriptor -> LDS ----------------------------------------
-        if (r <= 2 * T) {
+        if (ro <= 2 * T) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int idx = tid + s2 * T;
-                if (idx < r) {
-                    cs_s[idx] = d_cs[s2];
-                    pe_s[idx] = d_pe[s2];
-                    col_s[idx] = d_col[s2];
+                const int l = tid + s2 * T;
+                if (l < ro) {
+                    cs_s[l] = d_cs[s2];
+                    pe_s[l] = d_pe[s2];
+                    col_s[l] = d_col[s2];
+                    if (MW)
+                        oidx_s[l] = d_oidx[s2];
                 }
             }
         } else {
-            for (int idx = tid; idx < r; idx += T) {
-                const int e = rs + idx;
-                cs_s[idx] = pb.row_cs[e];
-                pe_s[idx] = pb.row_pos[e];
-                col_s[idx] = pb.row_col[e];
+            for (int l = tid; l < ro; l += T) {
+                const int e = MW ? pb.sub_e[os + l] : rs + l;
+                cs_s[l] = pb.row_cs[e];
+                pe_s[l] = pb.row_pos[e];
+                col_s[l] = pb.row_col[e];
+                if (MW)
+                    oidx_s[l] = e - rs;
             }
         }
+        if (MW)
+            for (int idx = tid; idx < r; idx += T)
+                loc_s[idx] = -1;
         if (it + 1 < nrows) {
             k_next = row_at(it + 1);
             rs_next = pb.row_ptr[k_next];
             re_next = pb.row_ptr[k_next + 1];
-            fetch_desc(rs_next, re_next - rs_next);
+            if (MW) {
+                os_next = sub_ptr[k_next];
+                oe_next = sub_ptr[k_next + 1];
+            }
+            fetch_desc(rs_next, MW ? oe_next - os_next : re_next - rs_next, os_next);
         }
         if (tid == 64 % T) { // row constants of select_variables, off thread 0
             misc_s[MS_BMIN] = pb.bmin[k];
@@ -1062,6 +1224,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             *(double*)(misc_s + MS_RBYTES) = pb.row_bytes[k];
         }
         __syncthreads();
+        if (MW)
+            for (int l = tid; l < ro; l += T)
+                loc_s[oidx_s[l]] = (short)l;
         BXH_STAMP(0);
 
         // ---- decrease_preference + compute_reduced_costs ------------------
@@ -1085,12 +1250,12 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             Float2 regP[LR][NP];
             unsigned regI[LR][NP]; // two 16-bit row indices per lane and piece
             const char* Pb = reinterpret_cast<const char*>(P);
-            const char* Ib = reinterpret_cast<const char*>(pb.col_row16);
+            const char* Ib = reinterpret_cast<const char*>(crow);
             auto issue = [&](int chunk) {
 #pragma unroll
                 for (int h = 0; h < LR; ++h) {
                     const int t = chunk * CW + h * 8 + g8;
-                    if (t < r) {
+                    if (t < ro) {
                         const int2 cs = cs_s[t];
                         const unsigned last = (unsigned)(cs.y >> 4) - 1u;
                         const unsigned q0 = (unsigned)cs.x + 2u * (unsigned)l8;
@@ -1109,7 +1274,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     }
                 }
             };
-            const int nchunks = (r + CW - 1) / CW;
+            const int nchunks = (ro + CW - 1) / CW;
             int chunk = wave;
             if (chunk < nchunks)
                 issue(chunk);
@@ -1117,7 +1282,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 #pragma unroll
                 for (int h = 0; h < LR; ++h) {
                     const int t = chunk * CW + h * 8 + g8;
-                    if (t < r) {
+                    if (t < ro) {
                         // every piece is stored; the adders only read the
                         // column's own (padded) length
                         Float* dp = wst_p + (h * 8 + g8) * SP + 2 * l8;
@@ -1142,7 +1307,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     const int u = lane & (CW - 1);
                     const bool is_pi = lane >= CW;
                     const int t = chunk * CW + u;
-                    if (t < r) {
+                    if (t < ro) {
                         const int2 cs = cs_s[t];
                         const int cpad = cs.y;
                         if (!is_pi) { // P[e] *= theta for this row's entry
@@ -1191,7 +1356,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                             }
                         }
                         if (is_pi)
-                            val_s[t] = acc;
+                            spi_s[t] = acc;
                         else
                             sp_s[t] = acc;
                     }
@@ -1205,14 +1370,41 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         __syncthreads();
         BXH_STAMP(2);
 
-        for (int idx = tid; idx < r; idx += T) {
-            const int j = col_s[idx];
-            Float v = cost[j] - val_s[idx] - sp_s[idx];
+        unsigned long long* xb =
+          MW ? st.xbuf + ((size_t)inst * 2 + (it & 1)) * pb.rmax : nullptr;
+        for (int l = tid; l < ro; l += T) {
+            const int idx = MW ? oidx_s[l] : l; // position in the whole row
+            const int j = col_s[l];
+            Float v = cost[j] - spi_s[l] - sp_s[l];
             if (PM1 && pb.fac_csr[rs + idx] < 0)
                 v = -v;
             if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
                 v += obj_amp * (PM1 ? cost[j] : cost[idx]);
-            val_s[idx] = v;
+            if (MW) // write-through store: the partners read it from L2
+                __hip_atomic_store(&xb[idx],
+                                   (unsigned long long)__double_as_longlong((double)v),
+                                   __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            else
+                val_s[idx] = v;
+        }
+        if (MW) {
+            // all-gather of the row's reduced costs among the owners: stores
+            // drained, one arrival per workgroup, one polling lane, then every
+            // value is read with an L1-bypassing load (the row-by-row protocol
+            // of the CDNA guide: sc1 payload -> vmcnt(0) -> barrier -> counter)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(cnt_row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wait_arrivals(cnt_row, (unsigned)NG * (unsigned)(it + 1), err_word);
+            }
+            __syncthreads();
+            for (int idx = tid; idx < r; idx += T) {
+                const unsigned long long bits =
+                  __hip_atomic_load(&xb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                val_s[idx] = (Float)__longlong_as_double((long long)bits);
+            }
         }
         const int n2 = next_pow2(r < 2 ? 2 : r);
         if (tid == 0) {
@@ -1457,11 +1649,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int idx = tid + s2 * T;
-                if (idx < r) {
-                    const int j = col_s[idx];
-                    const int pe = pe_s[idx];
-                    bool up = mode == 1 || (mode == 2 && mykey[s2] <= thr);
+                const int l = tid + s2 * T; // own entries only
+                if (l < ro) {
+                    const int idx = MW ? oidx_s[l] : l;
+                    const unsigned long long key =
+                      MW ? order_key<Float>(val_s[idx], maximize) : mykey[s2];
+                    const int j = col_s[l];
+                    const int pe = pe_s[l];
+                    bool up = mode == 1 || (mode == 2 && key <= thr);
                     if (PM1 && pb.fac_csr[rs + idx] < 0)
                         up = !up;
                     const Float p = P[pe] * theta;
@@ -1472,10 +1667,13 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
                         P[pe] = p - d;
                     }
-                    // R[idx].value after the sort only matters through
-                    // stop_iterating: keep its class (N / zero / S)
+                }
+                // R[pos].value after the sort only matters through
+                // stop_iterating: keep its class (N / zero / S)
+                const int pos = tid + s2 * T;
+                if (pos < r) {
                     const Float repN = maximize ? (Float)1 : (Float)-1;
-                    stale_s[idx] = idx < nN ? repN : (idx < nN + nZ ? (Float)0 : -repN);
+                    stale_s[pos] = pos < nN ? repN : (pos < nN + nZ ? (Float)0 : -repN);
                 }
             }
             __syncthreads();
@@ -1581,8 +1779,12 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             const Float d = *d_s;
             for (int i = tid; i < r; i += T) {
                 const int idx = id_s[i];
-                const int j = col_s[idx];
-                const int pe = pe_s[idx];
+                stale_s[i] = val_s[idx];
+                const int l = MW ? (int)loc_s[idx] : idx; // own entry?
+                if (l < 0)
+                    continue;
+                const int j = col_s[l];
+                const int pe = pe_s[l];
                 bool up = i <= sel;
                 if (PM1 && pb.fac_csr[rs + idx] < 0)
                     up = !up;
@@ -1594,30 +1796,53 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
                     P[pe] = p - d;
                 }
-                stale_s[i] = val_s[idx];
             }
         }
         __syncthreads();
         BXH_STAMP(6);
     }
 
-    for (int i = tid; i < pb.m; i += T)
-        pig[i] = pi_s[i];
-    for (int i = tid; i < 2 * pb.nwords; i += T)
-        xg[i] = x_s[i];
-    for (int i = tid; i <= pb.rmax; i += T)
-        staleg[i] = stale_s[i];
-
-    const int cnt = rebuild_violated(
-      pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES);
+    if (grp == 0) {
+        for (int i = tid; i < pb.m; i += T)
+            pig[i] = pi_s[i];
+        for (int i = tid; i <= pb.rmax; i += T)
+            staleg[i] = stale_s[i];
+    }
+    int cnt;
+    if (MW) {
+        // every owner merges the x bits of its columns into the shared words
+        const unsigned* own = pb.ownmask + (size_t)grp * (2 * pb.nwords);
+        for (int i = tid; i < 2 * pb.nwords; i += T) {
+            const unsigned mk = own[i];
+            if (mk) {
+                atomicAnd(&xg[i], ~mk);
+                atomicOr(&xg[i], x_s[i] & mk);
+            }
+        }
+        cnt = rebuild_violated_owners(pb,
+                                      grp,
+                                      NG,
+                                      x_s,
+                                      st.vpart + (size_t)inst * NG * pb.m,
+                                      cnt_end,
+                                      err_word,
+                                      st.vflag + ((size_t)inst * NG + grp) * pb.m,
+                                      grp == 0 ? vlist : vrows,
+                                      misc_s + MS_WAVES);
+    } else {
+        for (int i = tid; i < 2 * pb.nwords; i += T)
+            xg[i] = x_s[i];
+        cnt = rebuild_violated(
+          pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES);
+    }
     BXH_STAMP(7);
 #ifdef BXH_PROFILE
-    if (tid == 0)
+    if (tid == 0 && grp == 0)
         for (int i = 0; i < 16; ++i)
             st.prof[(size_t)inst * 16 + i] += prof.acc[i];
 #endif
 
-    if (tid == 0) {
+    if (tid == 0 && grp == 0) {
         st.vcount[inst] = cnt;
         DevStatus s = st.status[inst];
         s.remaining = cnt;

@@ -73,10 +73,13 @@ def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweep
     dev.close()
 
 
+@pytest.mark.parametrize("groups", ["1", "2", "4"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_sweeps_match_oracle(oracle, bxh, case, monkeypatch):
-    """Default kernel choice (staged column loads where the instance fits)."""
+def test_sweeps_match_oracle(oracle, bxh, case, groups, monkeypatch):
+    """Staged kernel, with 1, 2 and 4 cooperating workgroups (column owners)
+    per instance: the result must not depend on how the columns are split."""
     monkeypatch.delenv("BXH_FORCE_V1", raising=False)
+    monkeypatch.setenv("BXH_GROUPS", groups)
     _, maker, float_type, maximize, order, x0p = case
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
 
@@ -90,9 +93,11 @@ def test_sweeps_match_oracle_lane_per_column_kernel(oracle, bxh, case, monkeypat
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
 
 
-def test_scpnrh_shaped_rows(oracle, bxh):
+@pytest.mark.parametrize("groups", ["1", "4"])
+def test_scpnrh_shaped_rows(oracle, bxh, groups, monkeypatch):
     """Rows of ~500 elements and columns of ~50 (the bench shape, fewer rows):
     several passes per row, more than one piece per column."""
+    monkeypatch.setenv("BXH_GROUPS", groups)
     inst = synth.make_scp(120, 10000, 0.05, "int", 31)
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=4, push_at=(2,))
     inst = synth.make_scp(100, 6000, 0.08, "real", 32)
