@@ -261,6 +261,21 @@ dpp_u64(unsigned long long v)
         V = OP(t_, V);                                                         \
     } while (0)
 
+// Reduction inside each row of 16 lanes only (DPP, no LDS traffic): the four
+// row results are then combined by LDS atomics of lanes 0, 16, 32, 48.
+#define BXH_ROW_REDUCE(V, OP)                                                  \
+    do {                                                                       \
+        unsigned long long t_;                                                 \
+        t_ = dpp_u64<0xB1>(V);                                                 \
+        V = OP(t_, V);                                                         \
+        t_ = dpp_u64<0x4E>(V);                                                 \
+        V = OP(t_, V);                                                         \
+        t_ = dpp_u64<0x141>(V);                                                \
+        V = OP(t_, V);                                                         \
+        t_ = dpp_u64<0x140>(V);                                                \
+        V = OP(t_, V);                                                         \
+    } while (0)
+
 __device__ inline unsigned long long
 umin64(unsigned long long a, unsigned long long b)
 {
@@ -1006,8 +1021,8 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
     o = al(o + (rmax + 1) * fsize);
     p.off_misc = o;
     o = al(o + 96 * 4);
-    p.off_part = o; // per-wave partial reductions of the sort-free selection
-    o = al(o + 16 * 8 * 8);
+    p.off_part = o; // partial reductions of the sort-free selection
+    o = al(o + (64 + 8) * 8);
     p.off_union = o;
     // staging: per slot np*16 (+2) Float and np*16 (+4) 16-bit row indices
     const int stage_p = al(slots * (np * 16 + 2) * fsize);
@@ -1222,6 +1237,12 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             misc_s[MS_BMAX] = pb.bmax[k];
             misc_s[MS_BNEG] = pb.bneg[k];
             *(double*)(misc_s + MS_RBYTES) = pb.row_bytes[k];
+            // slots of the selection's LDS-atomic reductions (part_s[64..])
+            part_s[64] = 0ull;  // largest key
+            part_s[65] = 0ull;  // largest N key
+            part_s[66] = ~0ull; // smallest S key
+            part_s[67] = 0ull;  // counts: N in the high half, Z in the low half
+            part_s[68] = 0ull;  // tie flag
         }
         __syncthreads();
         if (MW)
@@ -1476,21 +1497,23 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 mn2 = own1 == mn1 ? own2 : own1;
                 mn2 = wave_min_u64(mn2);
             }
-            mx1 = wave_max_u64(mx1);
-            mxN = wave_max_u64(mxN);
-            mnS = wave_min_u64(mnS);
+            BXH_ROW_REDUCE(mx1, umax64);
+            BXH_ROW_REDUCE(mxN, umax64);
+            BXH_ROW_REDUCE(mnS, umin64);
             const bool wtie = __ballot(tie) != 0ull;
             {
                 const int wave = tid >> 6, lane = tid & 63;
-                unsigned long long* part = part_s + wave * 8;
+                if ((lane & 15) == 0) { // the four row leaders of the wave
+                    atomicMax(&part_s[64], mx1);
+                    atomicMax(&part_s[65], mxN);
+                    atomicMin(&part_s[66], mnS);
+                }
                 if (lane == 0) {
-                    part[0] = mn1;
-                    part[1] = mn2;
-                    part[2] = mx1;
-                    part[3] = mxN;
-                    part[4] = mnS;
-                    part[5] = ((unsigned long long)(unsigned)cN << 32) | (unsigned)cZ;
-                    part[6] = wtie ? 1ull : 0ull;
+                    part_s[wave * 2] = mn1;
+                    part_s[wave * 2 + 1] = mn2;
+                    atomicAdd(&part_s[67], ((unsigned long long)(unsigned)cN << 32) | (unsigned)cZ);
+                    if (wtie)
+                        atomicOr(&part_s[68], 1ull);
                 }
             }
             BXH_STAMP(8);
@@ -1502,36 +1525,20 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             // copies of the engine state (re-read after a sort-path row).
             {
                 const int nw = T >> 6;
-                const int lane = tid & 63;
-                const bool lv = lane < nw;
-                const unsigned long long* part = part_s + (lv ? lane : 0) * 8;
-                unsigned long long g1 = lv ? part[0] : ~0ull, g2 = lv ? part[1] : ~0ull;
-                unsigned long long gx = lv ? part[2] : 0ull, gxN = lv ? part[3] : 0ull;
-                unsigned long long gnS = lv ? part[4] : ~0ull;
-                unsigned long long cnt = lv ? part[5] : 0ull; // counts add without carry
-                unsigned long long tflag = lv ? part[6] : 0ull;
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) { // nw <= 16
-                    const unsigned long long b1 = __shfl_xor(g1, o, 64);
-                    const unsigned long long b2 = __shfl_xor(g2, o, 64);
-                    const unsigned long long lo1 = umin64(b1, g1), hi1 = umax64(b1, g1);
-                    g2 = umin64(hi1, umin64(b2, g2));
+                // two smallest keys: merge of the waves' sorted pairs
+                unsigned long long g1 = ~0ull, g2 = ~0ull;
+                for (int w = 0; w < nw; ++w) {
+                    const unsigned long long a1 = part_s[w * 2], a2 = part_s[w * 2 + 1];
+                    const unsigned long long lo1 = umin64(a1, g1), hi1 = umax64(a1, g1);
+                    g2 = umin64(hi1, umin64(a2, g2));
                     g1 = lo1;
-                    gx = umax64(gx, __shfl_xor(gx, o, 64));
-                    gxN = umax64(gxN, __shfl_xor(gxN, o, 64));
-                    gnS = umin64(gnS, __shfl_xor(gnS, o, 64));
-                    cnt += __shfl_xor(cnt, o, 64);
-                    tflag |= __shfl_xor(tflag, o, 64);
                 }
-                g1 = bcast_first_u64(g1);
-                g2 = bcast_first_u64(g2);
-                gx = bcast_first_u64(gx);
-                gxN = bcast_first_u64(gxN);
-                gnS = bcast_first_u64(gnS);
-                cnt = bcast_first_u64(cnt);
-                tflag = bcast_first_u64(tflag);
+                const unsigned long long gx = part_s[64], gxN = part_s[65], gnS = part_s[66];
+                const unsigned long long cnt = part_s[67];
+                const unsigned long long tflag = part_s[68];
                 const int nN = (int)(cnt >> 32), nZ = (int)(cnt & 0xffffffffu);
                 const bool anytie = tflag != 0ull;
+                BXH_STAMP(4);
                 bool ok = !anytie;
                 const unsigned saved_rng = rng.s;
                 int sel = 0;
@@ -1601,6 +1608,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         k_sel1 = key_at(sel + 1, ok);
                     }
                 }
+                BXH_STAMP(5);
                 if (!ok) {
                     rng.s = saved_rng; // the sort path redoes the scan
                 } else {

@@ -24,7 +24,7 @@ cost = normalize_costs(inst.dense_costs(), 4, float_type)
 delta = compute_delta(cost, 0.5, float_type)
 dev = _ffi.DeviceBatch(inst, cost, batch, float_type=float_type)
 x0 = np.zeros((batch, dev.nwords), np.uint64)
-names = ["desc", "fast:select", "rc:final-barrier", "combine", "sort:other", "thread0", "affect", "violated",
+names = ["desc", "fast:select", "rc:final-barrier", "combine", "sort:other|fast:merge-partials", "thread0|fast:scan+keys", "affect", "violated",
          "sort:wave-bitonic|fast:keys+hash+reduce", "sort:barrier1|fast:barrier", "sort:rank-search|fast:thread0", "sort:barrier2",
          "rc:wait+stage", "rc:issue", "rc:sum", "rc:tail"]
 for step in range(4):
