@@ -80,6 +80,7 @@ struct bxh_handle_s
     int nb = 0;                // v2: 16-entry pieces per staged column
     int groups = 1;            // v2: workgroups (column owners) per instance
     int romax = 0;             // longest per-owner part of a row
+    unsigned epoch = 0;        // sweep launches so far (tags of the row exchange)
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -90,6 +91,7 @@ struct bxh_handle_s
     DevBuf<signed char> fac_csr;
     DevBuf<unsigned short> col_row16;
     DevBuf<int> sub_ptr, sub_e;      // per-owner row parts (groups > 1)
+    DevBuf<int4> sub_desc;
     DevBuf<unsigned> ownmask;        // [groups][2*nwords] x bits of each owner
     DevBuf<int> vwork, vpart;        // [batch][groups][m]
     DevBuf<unsigned long long> xbuf; // [batch][2][rmax] reduced-cost exchange
@@ -98,6 +100,7 @@ struct bxh_handle_s
     DevBuf<double> row_bytes;   // [m]
     // host copies needed for state import/export and accounting
     std::vector<int> h_row_pos, h_row_ptr, h_col_ptr, h_row_col;
+    std::vector<unsigned char> h_owner; // owner workgroup of column j
 
     // state
     DevBuf<unsigned char> P, pi, rstale;
@@ -382,14 +385,52 @@ bxh_create(const bxh_problem* pb,
     }
     h->groups = groups;
 
-    // Device CSC, per owner (column j belongs to workgroup j % groups): every
+    // Column owners.  Every owner should hold about r_k / groups entries of
+    // EVERY row (the partners of an instance wait for the slowest one at each
+    // row): greedy assignment, each column goes to the owner that is least
+    // loaded over the rows the column touches.
+    std::vector<unsigned char> owner(static_cast<size_t>(n), 0);
+    if (groups > 1) {
+        std::vector<int> csc_rows(static_cast<size_t>(nnz));
+        {
+            std::vector<int> fill(col_ptr.begin(), col_ptr.end() - 1);
+            for (int k = 0; k != m; ++k)
+                for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e)
+                    csc_rows[fill[pb->col[e]]++] = k;
+        }
+        std::vector<int> load(static_cast<size_t>(m) * groups, 0);
+        std::vector<long long> total(static_cast<size_t>(groups), 0);
+        for (int j = 0; j != n; ++j) {
+            int best = 0;
+            long long best_score = -1;
+            for (int g = 0; g != groups; ++g) {
+                long long score = 0;
+                for (int q = col_ptr[j]; q != col_ptr[j + 1]; ++q) {
+                    const long long l = load[static_cast<size_t>(csc_rows[q]) * groups + g];
+                    score += l * l; // penalise the rows where g is already ahead
+                }
+                score = score * 4096 + total[g] % 4096;
+                if (best_score < 0 || score < best_score) {
+                    best_score = score;
+                    best = g;
+                }
+            }
+            owner[j] = static_cast<unsigned char>(best);
+            for (int q = col_ptr[j]; q != col_ptr[j + 1]; ++q)
+                ++load[static_cast<size_t>(csc_rows[q]) * groups + best];
+            total[best] += col_ptr[j + 1] - col_ptr[j];
+        }
+    }
+    h->h_owner = owner;
+
+    // Device CSC, per owner: every
     // column padded to a multiple of 16 entries (128 bytes of fp64 P), so a
     // column is a whole number of cache-line pieces.  Padding slots hold row
     // index m (pi_s[m] == 0 on the device) and P == 0 for ever.
     std::vector<int> col_start(static_cast<size_t>(n)), col_len(static_cast<size_t>(n));
     std::vector<long long> gsize(static_cast<size_t>(groups), 0);
     for (int j = 0; j != n; ++j) {
-        const int g = j % groups;
+        const int g = owner[j];
         col_start[j] = static_cast<int>(gsize[g]);
         col_len[j] = col_ptr[j + 1] - col_ptr[j];
         gsize[g] += std::max(16, (col_len[j] + 15) & ~15);
@@ -406,7 +447,7 @@ bxh_create(const bxh_problem* pb,
             for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e) {
                 const int j = pb->col[e];
                 const int q = fill[j]++;
-                const size_t at = static_cast<size_t>(j % groups) * nnzp + q;
+                const size_t at = static_cast<size_t>(owner[j]) * nnzp + q;
                 col_row[at] = k;
                 row_pos[e] = q;
                 if (pm1) {
@@ -428,7 +469,7 @@ bxh_create(const bxh_problem* pb,
             for (int k = 0; k != m; ++k) {
                 sub_ptr[static_cast<size_t>(g) * (m + 1) + k] = static_cast<int>(sub_e.size());
                 for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e)
-                    if (pb->col[e] % groups == g)
+                    if (owner[pb->col[e]] == g)
                         sub_e.push_back(e);
                 const int len = static_cast<int>(sub_e.size()) -
                                 sub_ptr[static_cast<size_t>(g) * (m + 1) + k];
@@ -438,9 +479,18 @@ bxh_create(const bxh_problem* pb,
             }
         ownmask.assign(static_cast<size_t>(groups) * 2 * h->nwords, 0u);
         for (int j = 0; j != n; ++j)
-            ownmask[static_cast<size_t>(j % groups) * 2 * h->nwords + (j >> 5)] |= 1u << (j & 31);
+            ownmask[static_cast<size_t>(owner[j]) * 2 * h->nwords + (j >> 5)] |= 1u << (j & 31);
     }
     h->romax = romax;
+    if (std::getenv("BXH_DEBUG") && groups > 1) {
+        long over = 0;
+        for (int g = 0; g != groups; ++g)
+            for (int k = 0; k != m; ++k)
+                over += sub_ptr[static_cast<size_t>(g) * (m + 1) + k + 1] -
+                          sub_ptr[static_cast<size_t>(g) * (m + 1) + k] > 128;
+        std::fprintf(stderr, "bxh: groups=%d rmax=%d romax=%d parts longer than 128: %ld of %d\n",
+                     groups, rmax, romax, over, groups * m);
+    }
 
     // ---- bounds as each Solver constructor clamps them --------------------
     std::vector<int> bmin(m), bmax(m), bneg(m, 0);
@@ -553,6 +603,14 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->fac_csr.upload(fac_csr));
     HIP_TRY(h->sub_ptr.upload(sub_ptr));
     HIP_TRY(h->sub_e.upload(sub_e));
+    {
+        std::vector<int4> sd(sub_e.size());
+        for (size_t t = 0; t != sub_e.size(); ++t) {
+            const int e = sub_e[t];
+            sd[t] = make_int4(row_cs[e].x, row_cs[e].y, row_pos[e], pb->col[e]);
+        }
+        HIP_TRY(h->sub_desc.upload(sd));
+    }
     HIP_TRY(h->ownmask.upload(ownmask));
     {
         std::vector<unsigned char> c;
@@ -578,7 +636,8 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->P.alloc(B * GG * nnzp * h->fsize));
     HIP_TRY(h->vwork.alloc(B * GG * m));
     HIP_TRY(h->vpart.alloc(B * GG * m));
-    HIP_TRY(h->xbuf.alloc(B * 2 * rmax));
+    HIP_TRY(h->xbuf.alloc(B * 2 * rmax * 2));
+    HIP_TRY(hipMemset(h->xbuf.p, 0, B * 2 * rmax * 2 * sizeof(unsigned long long)));
     HIP_TRY(h->cnt.alloc(2 * B + 1));
     HIP_TRY(hipMemset(h->cnt.p, 0, (2 * B + 1) * sizeof(unsigned)));
     HIP_TRY(h->pi.alloc(B * m * h->fsize));
@@ -669,6 +728,7 @@ bxh_create(const bxh_problem* pb,
     dp.romax = romax;
     dp.sub_ptr = h->sub_ptr.p;
     dp.sub_e = h->sub_e.p;
+    dp.sub_desc = h->sub_desc.p;
     dp.ownmask = h->ownmask.p;
     dp.rmax = rmax;
     dp.cmax = cmax;
@@ -814,7 +874,7 @@ bxh_set_P(bxh_handle h, int inst, const double* v)
     const size_t slice = static_cast<size_t>(h->nnzp), all = slice * h->groups;
     std::vector<double> csc(all, 0.0); // padding stays 0
     for (int e = 0; e != h->nnz; ++e)
-        csc[static_cast<size_t>(h->h_row_col[e] % h->groups) * slice + h->h_row_pos[e]] = v[e];
+        csc[static_cast<size_t>(h->h_owner[h->h_row_col[e]]) * slice + h->h_row_pos[e]] = v[e];
     return set_vec(h, h->P.p + static_cast<size_t>(inst) * all * h->fsize, csc.data(), all);
 }
 
@@ -828,7 +888,7 @@ bxh_get_P(bxh_handle h, int inst, double* v)
     if (int rc = get_vec(h, h->P.p + static_cast<size_t>(inst) * all * h->fsize, csc.data(), all))
         return rc;
     for (int e = 0; e != h->nnz; ++e)
-        v[e] = csc[static_cast<size_t>(h->h_row_col[e] % h->groups) * slice + h->h_row_pos[e]];
+        v[e] = csc[static_cast<size_t>(h->h_owner[h->h_row_col[e]]) * slice + h->h_row_pos[e]];
     return BXH_OK;
 }
 
@@ -966,9 +1026,14 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
                                h->stream));
         s.active = h->active.p;
     }
-    if (h->groups > 1) // arrival counters of the cooperating workgroups
+    if (h->groups > 1) { // arrival counters of the cooperating workgroups
         HIP_TRY(hipMemsetAsync(h->cnt.p, 0, 2 * static_cast<size_t>(h->batch) * sizeof(unsigned),
                                h->stream));
+        if ((++h->epoch & 0x1ffffu) == 0) // tag space wrapped: forget old granules
+            HIP_TRY(hipMemsetAsync(h->xbuf.p, 0, h->xbuf.count * sizeof(unsigned long long),
+                                   h->stream));
+    }
+    s.epoch = h->epoch;
     return h->float_type == BXH_FLOAT ? launch_sweep<float>(h, s)
                                       : launch_sweep<double>(h, s);
 }

@@ -45,6 +45,8 @@ struct DevProblem
                                //         only when m < 32768 (v2 kernel)
     const int* sub_ptr;        // [groups][m+1] per-owner part of row k in sub_e
     const int* sub_e;          // CSR element ids, row order, owner after owner
+    const int4* sub_desc;      // per sub_e slot: {first CSC slot, padded length,
+                               //  CSC slot of the entry, column}: one load per entry
     const unsigned* ownmask;   // [groups][2*nwords] x bits of each owner
     const signed char* fac_csr; // [nnz]  coefficient of CSR element (101 kinds)
     const int* bmin;           // [m] clamped as the Solver constructor does
@@ -78,7 +80,7 @@ struct DevState
     unsigned long long* prof; // [batch][16] phase ticks (profiling build only)
     int* vwork;          // [batch][groups][m] private copy of the row list
     int* vpart;          // [batch][groups][m] per-owner row activities
-    unsigned long long* xbuf; // [batch][2][rmax] reduced costs of the current row
+    unsigned long long* xbuf; // [batch][2][rmax][2] tagged halves of the row's reduced costs
     unsigned* cnt;       // [batch] row arrivals, [batch] sweep-end arrivals, [1] error
 };
 
@@ -123,6 +125,7 @@ struct DevSweep
     int is_push;
     int order;
     const unsigned char* active; // [batch] or null
+    unsigned epoch;              // launch number (tags of the row exchange)
 };
 
 // ---------------------------------------------------------------------------
@@ -1163,12 +1166,25 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     auto row_at = [&](int it_) -> int {
         return (a.order == 1) ? vrows[nrows - 1 - it_] : vrows[it_];
     };
-    int k_next = nrows > 0 ? row_at(0) : 0;
-    int rs_next = nrows > 0 ? pb.row_ptr[k_next] : 0;
-    int re_next = nrows > 0 ? pb.row_ptr[k_next + 1] : 0;
+    // row extents travel TWO rows ahead (k -> row_ptr / sub_ptr are dependent
+    // scalar loads), the per-entry descriptor one row ahead
     const int* sub_ptr = MW ? pb.sub_ptr + (size_t)grp * (pb.m + 1) : nullptr;
-    int os_next = (MW && nrows > 0) ? sub_ptr[k_next] : 0;
-    int oe_next = (MW && nrows > 0) ? sub_ptr[k_next + 1] : 0;
+    int k_next = 0, rs_next = 0, re_next = 0, os_next = 0, oe_next = 0; // row it + 1
+    int k_nn = 0, rs_nn = 0, re_nn = 0, os_nn = 0, oe_nn = 0;           // row it + 2
+    int k_q = nrows > 2 ? row_at(2) : 0; // row id of row it + 3 (no dependency)
+    auto row_extent = [&](int kid, int& k_, int& rs_, int& re_, int& os_, int& oe_) {
+        k_ = kid;
+        rs_ = pb.row_ptr[k_];
+        re_ = pb.row_ptr[k_ + 1];
+        if (MW) {
+            os_ = sub_ptr[k_];
+            oe_ = sub_ptr[k_ + 1];
+        }
+    };
+    if (nrows > 0)
+        row_extent(row_at(0), k_next, rs_next, re_next, os_next, oe_next);
+    if (nrows > 1)
+        row_extent(row_at(1), k_nn, rs_nn, re_nn, os_nn, oe_nn);
     // the next row's descriptor (column start / padded length, CSC slot and
     // column of each element) travels in registers while this row is worked on
     int2 d_cs[2];
@@ -1178,16 +1194,37 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         for (int s2 = 0; s2 < 2; ++s2) {
             const int l = tid + s2 * T;
             if (l < ro_) {
-                const int e = MW ? pb.sub_e[os_ + l] : rs_ + l;
-                d_cs[s2] = pb.row_cs[e];
-                d_pe[s2] = pb.row_pos[e];
-                d_col[s2] = pb.row_col[e];
-                d_oidx[s2] = e - rs_;
+                if (MW) { // independent loads: no pointer chase per entry
+                    const int4 dd = pb.sub_desc[os_ + l];
+                    d_cs[s2] = make_int2(dd.x, dd.y);
+                    d_pe[s2] = dd.z;
+                    d_col[s2] = dd.w;
+                    d_oidx[s2] = pb.sub_e[os_ + l] - rs_;
+                } else {
+                    const int e = rs_ + l;
+                    d_cs[s2] = pb.row_cs[e];
+                    d_pe[s2] = pb.row_pos[e];
+                    d_col[s2] = pb.row_col[e];
+                    d_oidx[s2] = l;
+                }
             }
         }
     };
-    if (nrows > 0)
+    // row constants of select_variables, fetched one row ahead by one thread
+    int c_bmin = 0, c_bmax = 0, c_bneg = 0;
+    double c_rbytes = 0.0;
+    auto fetch_consts = [&](int k_) {
+        if (tid == 64 % T) {
+            c_bmin = pb.bmin[k_];
+            c_bmax = pb.bmax[k_];
+            c_bneg = pb.bneg[k_];
+            c_rbytes = pb.row_bytes[k_];
+        }
+    };
+    if (nrows > 0) {
         fetch_desc(rs_next, MW ? oe_next - os_next : re_next - rs_next, os_next);
+        fetch_consts(k_next);
+    }
 
     for (int it = 0; it < nrows; ++it) {
         const int k = k_next;
@@ -1222,21 +1259,27 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         if (MW)
             for (int idx = tid; idx < r; idx += T)
                 loc_s[idx] = -1;
+        BXH_STAMP(11);
         if (it + 1 < nrows) {
-            k_next = row_at(it + 1);
-            rs_next = pb.row_ptr[k_next];
-            re_next = pb.row_ptr[k_next + 1];
-            if (MW) {
-                os_next = sub_ptr[k_next];
-                oe_next = sub_ptr[k_next + 1];
-            }
+            k_next = k_nn;
+            rs_next = rs_nn;
+            re_next = re_nn;
+            os_next = os_nn;
+            oe_next = oe_nn;
             fetch_desc(rs_next, MW ? oe_next - os_next : re_next - rs_next, os_next);
+            if (it + 2 < nrows) {
+                // k_q was loaded during the previous row: its dependent loads
+                // can be issued without waiting
+                row_extent(k_q, k_nn, rs_nn, re_nn, os_nn, oe_nn);
+                if (it + 3 < nrows)
+                    k_q = row_at(it + 3);
+            }
         }
         if (tid == 64 % T) { // row constants of select_variables, off thread 0
-            misc_s[MS_BMIN] = pb.bmin[k];
-            misc_s[MS_BMAX] = pb.bmax[k];
-            misc_s[MS_BNEG] = pb.bneg[k];
-            *(double*)(misc_s + MS_RBYTES) = pb.row_bytes[k];
+            misc_s[MS_BMIN] = c_bmin;
+            misc_s[MS_BMAX] = c_bmax;
+            misc_s[MS_BNEG] = c_bneg;
+            *(double*)(misc_s + MS_RBYTES) = c_rbytes;
             // slots of the selection's LDS-atomic reductions (part_s[64..])
             part_s[64] = 0ull;  // largest key
             part_s[65] = 0ull;  // largest N key
@@ -1244,6 +1287,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             part_s[67] = 0ull;  // counts: N in the high half, Z in the low half
             part_s[68] = 0ull;  // tie flag
         }
+        if (it + 1 < nrows)
+            fetch_consts(k_next);
+        BXH_STAMP(1);
         __syncthreads();
         if (MW)
             for (int l = tid; l < ro; l += T)
@@ -1391,8 +1437,16 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         __syncthreads();
         BXH_STAMP(2);
 
+        // Row exchange among the owners: every reduced cost travels as two
+        // naturally aligned 8-byte granules {32 value bits, 32-bit tag}, each
+        // written by ONE write-through store and read with L1-bypassing loads
+        // until its tag is the current (launch, row) number -- no counter, no
+        // barrier, one L2 round trip.  Two slots alternate: a workgroup can
+        // only be one row ahead of its partners (it needs their values).
         unsigned long long* xb =
-          MW ? st.xbuf + ((size_t)inst * 2 + (it & 1)) * pb.rmax : nullptr;
+          MW ? st.xbuf + (((size_t)inst * 2 + (it & 1)) * pb.rmax) * 2 : nullptr;
+        const unsigned long long tag =
+          (unsigned long long)(((a.epoch & 0x1ffffu) << 15) | (unsigned)(it + 1)) << 32;
         for (int l = tid; l < ro; l += T) {
             const int idx = MW ? oidx_s[l] : l; // position in the whole row
             const int j = col_s[l];
@@ -1401,29 +1455,33 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 v = -v;
             if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
                 v += obj_amp * (PM1 ? cost[j] : cost[idx]);
-            if (MW) // write-through store: the partners read it from L2
-                __hip_atomic_store(&xb[idx],
-                                   (unsigned long long)__double_as_longlong((double)v),
-                                   __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            else
+            if (MW) {
+                const unsigned long long bits =
+                  (unsigned long long)__double_as_longlong((double)v);
+                __hip_atomic_store(&xb[2 * idx], (bits & 0xffffffffull) | tag,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&xb[2 * idx + 1], (bits >> 32) | tag,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
                 val_s[idx] = v;
+            }
         }
         if (MW) {
-            // all-gather of the row's reduced costs among the owners: stores
-            // drained, one arrival per workgroup, one polling lane, then every
-            // value is read with an L1-bypassing load (the row-by-row protocol
-            // of the CDNA guide: sc1 payload -> vmcnt(0) -> barrier -> counter)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __hip_atomic_fetch_add(cnt_row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wait_arrivals(cnt_row, (unsigned)NG * (unsigned)(it + 1), err_word);
-            }
-            __syncthreads();
             for (int idx = tid; idx < r; idx += T) {
-                const unsigned long long bits =
-                  __hip_atomic_load(&xb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long lo, hi;
+                long spins = 0;
+                for (;;) {
+                    lo = __hip_atomic_load(&xb[2 * idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi = __hip_atomic_load(&xb[2 * idx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((lo & 0xffffffff00000000ull) == tag && (hi & 0xffffffff00000000ull) == tag)
+                        break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 2000000L) { // a partner is missing: give up loudly
+                        __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                const unsigned long long bits = (lo & 0xffffffffull) | (hi << 32);
                 val_s[idx] = (Float)__longlong_as_double((long long)bits);
             }
         }
