@@ -92,6 +92,7 @@ struct bxh_handle_s
     DevBuf<unsigned short> col_row16;
     DevBuf<int> sub_ptr, sub_e;      // per-owner row parts (groups > 1)
     DevBuf<int4> sub_desc;
+    DevBuf<unsigned char> desc_cost; // cost of each descriptor's column (Float)
     DevBuf<unsigned> ownmask;        // [groups][2*nwords] x bits of each owner
     DevBuf<int> vwork, vpart;        // [batch][groups][m]
     DevBuf<unsigned long long> xbuf; // [batch][2][rmax] reduced-cost exchange
@@ -243,6 +244,8 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
         if (pm1) {
             if (h->nb == 4)
                 BXH_V2(true, 4);
+            else if (h->nb == 5)
+                BXH_V2(true, 5);
             else if (h->nb == 6)
                 BXH_V2(true, 6);
             else
@@ -250,6 +253,8 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
         } else {
             if (h->nb == 4)
                 BXH_V2(false, 4);
+            else if (h->nb == 5)
+                BXH_V2(false, 5);
             else if (h->nb == 6)
                 BXH_V2(false, 6);
             else
@@ -542,10 +547,37 @@ bxh_create(const bxh_problem* pb,
     }
 
     // ---- launch geometry ----------------------------------------------------
+    // row_cs[e] = { first padded CSC slot of the column, padded length | the
+    // largest piece count among the 16 descriptors of its staging chunk << 16 }:
+    // a wave loads that many 16-entry pieces for every column of the chunk
     std::vector<int2> row_cs(static_cast<size_t>(nnz));
     for (int e = 0; e != nnz; ++e) {
         const int j = pb->col[e];
         row_cs[e] = make_int2(col_start[j], std::max(16, (col_len[j] + 15) & ~15));
+    }
+    auto mark_chunks = [&](const int* ids, int count) { // one row (or owner part)
+        for (int c0 = 0; c0 < count; c0 += 16) {
+            int mx = 1;
+            for (int l = c0; l < std::min(count, c0 + 16); ++l)
+                mx = std::max(mx, (row_cs[ids[l]].y & 0xffff) >> 4);
+            for (int l = c0; l < std::min(count, c0 + 16); ++l)
+                row_cs[ids[l]].y = (row_cs[ids[l]].y & 0xffff) | (mx << 16);
+        }
+    };
+    if (groups > 1) {
+        for (int g = 0; g != groups; ++g)
+            for (int k = 0; k != m; ++k) {
+                const size_t at = static_cast<size_t>(g) * (m + 1) + k;
+                mark_chunks(sub_e.data() + sub_ptr[at], sub_ptr[at + 1] - sub_ptr[at]);
+            }
+    } else {
+        std::vector<int> ids(static_cast<size_t>(rmax));
+        for (int k = 0; k != m; ++k) {
+            const int len = pb->row_ptr[k + 1] - pb->row_ptr[k];
+            for (int l = 0; l != len; ++l)
+                ids[l] = pb->row_ptr[k] + l;
+            mark_chunks(ids.data(), len);
+        }
     }
 
     const int lds_limit = 160 * 1024;
@@ -561,7 +593,7 @@ bxh_create(const bxh_problem* pb,
     h->lds_bytes = static_cast<size_t>(lp.total);
     h->threads = std::min(1024, std::max(64, bxh::next_pow2(rmax)));
     if (v2_ok) {
-        const int np = cmax <= 64 ? 4 : (cmax <= 96 ? 6 : 8);
+        const int np = cmax <= 64 ? 4 : (cmax <= 80 ? 5 : (cmax <= 96 ? 6 : 8));
         // 16 staging slots per wave; as many waves (up to 8) as LDS allows
         for (int t = 512; t >= 128; t >>= 1) {
             const bxh::LdsPlan2 lp2 = bxh::lds_plan2(m, h->nwords, rmax, romax,
@@ -619,6 +651,17 @@ bxh_create(const bxh_problem* pb,
         else
             to_float<double>(pb->cost, n, c);
         HIP_TRY(h->cost.upload(c));
+        // the same costs in descriptor order (per owner part, or CSR order
+        // with one owner): an independent load next to the descriptor
+        std::vector<double> dc(static_cast<size_t>(nnz));
+        for (int t = 0; t != nnz; ++t)
+            dc[t] = pb->cost[pb->col[groups > 1 ? sub_e[t] : t]];
+        std::vector<unsigned char> c2;
+        if (float_type == BXH_FLOAT)
+            to_float<float>(dc.data(), dc.size(), c2);
+        else
+            to_float<double>(dc.data(), dc.size(), c2);
+        HIP_TRY(h->desc_cost.upload(c2));
     }
     h->h_row_pos = std::move(row_pos);
     h->h_row_ptr.assign(pb->row_ptr, pb->row_ptr + m + 1);
@@ -693,24 +736,32 @@ bxh_create(const bxh_problem* pb,
             BXH_SET_LDS((bxh::order_init_kernel<double>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 5, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 5, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 5, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 5, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 5, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 5, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 5, false>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 5, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, false>));
@@ -729,6 +780,7 @@ bxh_create(const bxh_problem* pb,
     dp.sub_ptr = h->sub_ptr.p;
     dp.sub_e = h->sub_e.p;
     dp.sub_desc = h->sub_desc.p;
+    dp.desc_cost = h->desc_cost.p;
     dp.ownmask = h->ownmask.p;
     dp.rmax = rmax;
     dp.cmax = cmax;

@@ -47,6 +47,7 @@ struct DevProblem
     const int* sub_e;          // CSR element ids, row order, owner after owner
     const int4* sub_desc;      // per sub_e slot: {first CSC slot, padded length,
                                //  CSC slot of the entry, column}: one load per entry
+    const void* desc_cost;     // [nnz] Float: cost of the descriptor's column
     const unsigned* ownmask;   // [groups][2*nwords] x bits of each owner
     const signed char* fac_csr; // [nnz]  coefficient of CSR element (101 kinds)
     const int* bmin;           // [m] clamped as the Solver constructor does
@@ -985,10 +986,12 @@ rebuild_violated_owners(const DevProblem& pb,
 
 struct LdsPlan2
 {
-    int off_pi, off_x, off_val, off_sp, off_cs, off_pe, off_col, off_spi, off_oidx,
-      off_loc, off_stale, off_misc, off_part, off_union, stage_i_off, total;
+    int off_pi, off_x, off_val, off_sp, off_cs, off_pe, off_col, off_cost, off_pown, off_spi,
+      off_oidx, off_loc, off_stale, off_misc, off_part, off_union, stage_i_off, total;
 };
 
+// The row descriptors (cs, pe, col, cost, oidx, loc) are double buffered: the
+// one of row it + 1 is written while the loads of row it are in flight.
 __host__ __device__ inline LdsPlan2
 lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, bool mw)
 {
@@ -1004,11 +1007,15 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
     p.off_sp = o;
     o = al(o + romax * fsize);
     p.off_cs = o;
-    o = al(o + romax * 8);
+    o = al(o + 2 * romax * 8);
     p.off_pe = o;
-    o = al(o + romax * 4);
+    o = al(o + 2 * romax * 4);
     p.off_col = o;
-    o = al(o + romax * 4);
+    o = al(o + 2 * romax * 4);
+    p.off_cost = o;
+    o = al(o + 2 * romax * fsize);
+    p.off_pown = o; // the row's own P entries after the decay
+    o = al(o + romax * fsize);
     p.off_spi = p.off_val; // one owner: the pi sums sit in val_s until combined
     p.off_oidx = o;
     p.off_loc = o;
@@ -1016,9 +1023,9 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
         p.off_spi = o;
         o = al(o + romax * fsize);
         p.off_oidx = o;
-        o = al(o + romax * 4);
+        o = al(o + 2 * romax * 4);
         p.off_loc = o;
-        o = al(o + rmax * 2);
+        o = al(o + 2 * rmax * 2);
     }
     p.off_stale = o;
     o = al(o + (rmax + 1) * fsize);
@@ -1078,11 +1085,15 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     Float* val_s = (Float*)(smem + lp.off_val);
     Float* sp_s = (Float*)(smem + lp.off_sp);
     Float* spi_s = (Float*)(smem + lp.off_spi); // == val_s with one owner
-    int* oidx_s = (int*)(smem + lp.off_oidx);   // MW: row position of own entry l
-    short* loc_s = (short*)(smem + lp.off_loc); // MW: own entry of row position, or -1
-    int2* cs_s = (int2*)(smem + lp.off_cs);
-    int* pe_s = (int*)(smem + lp.off_pe);
-    int* col_s = (int*)(smem + lp.off_col);
+    // double-buffered row descriptors (buffer it & 1 holds row it)
+    const int RO = MW ? pb.romax : pb.rmax;
+    int2* const cs_b = (int2*)(smem + lp.off_cs);
+    int* const pe_b = (int*)(smem + lp.off_pe);
+    int* const col_b = (int*)(smem + lp.off_col);
+    Float* const cost_b = (Float*)(smem + lp.off_cost);
+    int* const oidx_b = (int*)(smem + lp.off_oidx);
+    short* const loc_b = (short*)(smem + lp.off_loc);
+    Float* pown_s = (Float*)(smem + lp.off_pown);
     Float* stale_s = (Float*)(smem + lp.off_stale);
     int* misc_s = (int*)(smem + lp.off_misc);
     Float* d_s = (Float*)(misc_s + MS_D);
@@ -1161,53 +1172,110 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     prof.t = wall_clock64();
 #endif
 
-    // row ids and extents one row ahead (three dependent global loads
-    // otherwise sit at the head of every row)
+    // Rows ahead.  k -> row_ptr / sub_ptr -> descriptor records are dependent
+    // global loads: the row id travels four rows ahead, the extents three, the
+    // per-entry descriptor (registers) two and its LDS copy one, so that none
+    // of them is waited for at the head of a row.
     auto row_at = [&](int it_) -> int {
         return (a.order == 1) ? vrows[nrows - 1 - it_] : vrows[it_];
     };
-    // row extents travel TWO rows ahead (k -> row_ptr / sub_ptr are dependent
-    // scalar loads), the per-entry descriptor one row ahead
     const int* sub_ptr = MW ? pb.sub_ptr + (size_t)grp * (pb.m + 1) : nullptr;
-    int k_next = 0, rs_next = 0, re_next = 0, os_next = 0, oe_next = 0; // row it + 1
-    int k_nn = 0, rs_nn = 0, re_nn = 0, os_nn = 0, oe_nn = 0;           // row it + 2
-    int k_q = nrows > 2 ? row_at(2) : 0; // row id of row it + 3 (no dependency)
-    auto row_extent = [&](int kid, int& k_, int& rs_, int& re_, int& os_, int& oe_) {
-        k_ = kid;
-        rs_ = pb.row_ptr[k_];
-        re_ = pb.row_ptr[k_ + 1];
-        if (MW) {
-            os_ = sub_ptr[k_];
-            oe_ = sub_ptr[k_ + 1];
-        }
+    struct RowX
+    {
+        int k, rs, re, os, oe;
     };
+    auto row_extent = [&](int kid) -> RowX {
+        RowX x;
+        x.k = kid;
+        x.rs = pb.row_ptr[kid];
+        x.re = pb.row_ptr[kid + 1];
+        x.os = MW ? sub_ptr[kid] : 0;
+        x.oe = MW ? sub_ptr[kid + 1] : 0;
+        return x;
+    };
+    auto own_len = [&](const RowX& x) -> int { return MW ? x.oe - x.os : x.re - x.rs; };
+    RowX x0 = { 0, 0, 0, 0, 0 }, x1 = x0, x2 = x0;
     if (nrows > 0)
-        row_extent(row_at(0), k_next, rs_next, re_next, os_next, oe_next);
+        x0 = row_extent(row_at(0));
     if (nrows > 1)
-        row_extent(row_at(1), k_nn, rs_nn, re_nn, os_nn, oe_nn);
-    // the next row's descriptor (column start / padded length, CSC slot and
-    // column of each element) travels in registers while this row is worked on
+        x1 = row_extent(row_at(1));
+    if (nrows > 2)
+        x2 = row_extent(row_at(2));
+    RowX x3 = x2;
+    int k3 = nrows > 3 ? row_at(3) : 0, k4 = 0;
+    // descriptor of a row's own entries (column start / padded length | chunk
+    // pieces, CSC slot, column, cost, position in the whole row) in registers
     int2 d_cs[2];
     int d_pe[2], d_col[2], d_oidx[2];
-    auto fetch_desc = [&](int rs_, int ro_, int os_) { // own entries l < ro_
+    Float d_cost[2];
+    auto fetch_desc = [&](const RowX& x) { // own entries l < ro_
+        const int ro_ = own_len(x);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int l = tid + s2 * T;
             if (l < ro_) {
                 if (MW) { // independent loads: no pointer chase per entry
-                    const int4 dd = pb.sub_desc[os_ + l];
+                    const int4 dd = pb.sub_desc[x.os + l];
                     d_cs[s2] = make_int2(dd.x, dd.y);
                     d_pe[s2] = dd.z;
                     d_col[s2] = dd.w;
-                    d_oidx[s2] = pb.sub_e[os_ + l] - rs_;
+                    d_oidx[s2] = pb.sub_e[x.os + l] - x.rs;
+                    d_cost[s2] = ((const Float*)pb.desc_cost)[x.os + l];
                 } else {
-                    const int e = rs_ + l;
+                    const int e = x.rs + l;
                     d_cs[s2] = pb.row_cs[e];
                     d_pe[s2] = pb.row_pos[e];
                     d_col[s2] = pb.row_col[e];
                     d_oidx[s2] = l;
+                    d_cost[s2] = ((const Float*)pb.desc_cost)[e];
                 }
             }
+        }
+    };
+    auto store_desc = [&](const RowX& x, int buf) { // registers -> LDS buffer
+        const int ro_ = own_len(x);
+        int2* cs_w = cs_b + buf * RO;
+        int* pe_w = pe_b + buf * RO;
+        int* col_w = col_b + buf * RO;
+        Float* cost_w = cost_b + buf * RO;
+        int* oidx_w = oidx_b + buf * RO;
+        if (ro_ <= 2 * T) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int l = tid + s2 * T;
+                if (l < ro_) {
+                    cs_w[l] = d_cs[s2];
+                    pe_w[l] = d_pe[s2];
+                    col_w[l] = d_col[s2];
+                    cost_w[l] = d_cost[s2];
+                    if (MW)
+                        oidx_w[l] = d_oidx[s2];
+                }
+            }
+        } else {
+            for (int l = tid; l < ro_; l += T) {
+                const int e = MW ? pb.sub_e[x.os + l] : x.rs + l;
+                cs_w[l] = pb.row_cs[e];
+                pe_w[l] = pb.row_pos[e];
+                col_w[l] = pb.row_col[e];
+                cost_w[l] = cost[pb.row_col[e]];
+                if (MW)
+                    oidx_w[l] = e - x.rs;
+            }
+        }
+        if (MW) { // own entry of a row position, filled in after the next barrier
+            short* loc_w = loc_b + buf * pb.rmax;
+            for (int idx = tid; idx < x.re - x.rs; idx += T)
+                loc_w[idx] = -1;
+        }
+    };
+    auto fill_loc = [&](const RowX& x, int buf) {
+        if (MW) {
+            const int ro_ = own_len(x);
+            short* loc_w = loc_b + buf * pb.rmax;
+            const int* oidx_w = oidx_b + buf * RO;
+            for (int l = tid; l < ro_; l += T)
+                loc_w[oidx_w[l]] = (short)l;
         }
     };
     // row constants of select_variables, fetched one row ahead by one thread
@@ -1222,142 +1290,104 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         }
     };
     if (nrows > 0) {
-        fetch_desc(rs_next, MW ? oe_next - os_next : re_next - rs_next, os_next);
-        fetch_consts(k_next);
+        fetch_desc(x0);
+        store_desc(x0, 0);
+        fetch_consts(x0.k);
+        if (nrows > 1)
+            fetch_desc(x1);
+        __syncthreads();
+        fill_loc(x0, 0);
     }
 
-    for (int it = 0; it < nrows; ++it) {
-        const int k = k_next;
-        const int rs = rs_next;
-        const int r = re_next - rs_next;              // the whole row
-        const int os = os_next;
-        const int ro = MW ? oe_next - os_next : r;    // this owner's entries
-
-        // ---- row descriptor -> LDS ----------------------------------------
-        if (ro <= 2 * T) {
+    // ---- reduced-cost pipeline: loads of a wave's chunk of 16 columns --------
+    // Columns are stored padded to 16 entries (128 bytes of P), so a column
+    // is a whole number of 16-entry pieces: an 8-lane group loads one piece
+    // per instruction (16 B of P + 4 B of row indices per lane = exactly one
+    // cache line of P).  Every column of a chunk loads the chunk's largest
+    // piece count (wave-uniform, from the descriptor); pieces past a column's
+    // own end re-read its last piece (a cache hit): no branch per lane and no
+    // use of the values at issue, so all loads stay in flight together.
+    constexpr int CW = 8 * LR; // columns of a wave's chunk
+    const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
+    const int g8 = lane >> 3;
+    Float* const wst_p = stg_p + wave * (CW * SP);
+    unsigned short* const wst_i = stg_i + wave * (CW * SI);
+    Float2 regP[LR][NP];
+    unsigned regI[LR][NP]; // two 16-bit row indices per lane and piece
+    const char* const Pb = reinterpret_cast<const char*>(P);
+    const char* const Ib = reinterpret_cast<const char*>(crow);
+    auto chunk_pieces = [&](const int2* cs_r, int chunk) -> int {
+        return __builtin_amdgcn_readfirstlane(cs_r[chunk * CW].y >> 16);
+    };
+    auto issue = [&](const int2* cs_r, int ro_, int chunk, int npm) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int l = tid + s2 * T;
-                if (l < ro) {
-                    cs_s[l] = d_cs[s2];
-                    pe_s[l] = d_pe[s2];
-                    col_s[l] = d_col[s2];
-                    if (MW)
-                        oidx_s[l] = d_oidx[s2];
+        for (int h = 0; h < LR; ++h) {
+            const int t = chunk * CW + h * 8 + g8;
+            if (t < ro_) {
+                const int2 cs = cs_r[t];
+                const unsigned last = (unsigned)((cs.y & 0xffff) >> 4) - 1u;
+                const unsigned q0 = (unsigned)cs.x + 2u * (unsigned)l8;
+#pragma unroll
+                for (int b = 0; b < NP; ++b) {
+                    if (b < npm) { // wave-uniform
+                        // 32-bit offsets from a uniform base
+                        const unsigned q = q0 + (min((unsigned)b, last) << 4);
+                        regP[h][b] =
+                          *reinterpret_cast<const Float2*>(Pb + q * (unsigned)sizeof(Float));
+                        regI[h][b] = *reinterpret_cast<const unsigned*>(Ib + q * 2u);
+                    }
                 }
             }
-        } else {
-            for (int l = tid; l < ro; l += T) {
-                const int e = MW ? pb.sub_e[os + l] : rs + l;
-                cs_s[l] = pb.row_cs[e];
-                pe_s[l] = pb.row_pos[e];
-                col_s[l] = pb.row_col[e];
-                if (MW)
-                    oidx_s[l] = e - rs;
-            }
         }
-        if (MW)
-            for (int idx = tid; idx < r; idx += T)
-                loc_s[idx] = -1;
-        BXH_STAMP(11);
-        if (it + 1 < nrows) {
-            k_next = k_nn;
-            rs_next = rs_nn;
-            re_next = re_nn;
-            os_next = os_nn;
-            oe_next = oe_nn;
-            fetch_desc(rs_next, MW ? oe_next - os_next : re_next - rs_next, os_next);
-            if (it + 2 < nrows) {
-                // k_q was loaded during the previous row: its dependent loads
-                // can be issued without waiting
-                row_extent(k_q, k_nn, rs_nn, re_nn, os_nn, oe_nn);
-                if (it + 3 < nrows)
-                    k_q = row_at(it + 3);
-            }
+    };
+
+    for (int it = 0; it < nrows; ++it, x0 = x1, x1 = x2, x2 = x3, k3 = k4) {
+        const int cur = it & 1;
+        const int k = x0.k;
+        const int rs = x0.rs;
+        const int r = x0.re - x0.rs;  // the whole row
+        const int ro = own_len(x0);   // this owner's entries
+        const int2* cs_s = cs_b + cur * RO;
+        const int* pe_s = pe_b + cur * RO;
+        const int* col_s = col_b + cur * RO;
+        const Float* cost_s = cost_b + cur * RO;
+        const int* oidx_s = oidx_b + cur * RO;
+        const short* loc_s = loc_b + cur * pb.rmax;
+
+        // ---- this row's first loads, then the next row's descriptor ---------
+        const int nchunks = (ro + CW - 1) / CW;
+        int chunk = wave;
+        int npm = 0;
+        if (chunk < nchunks) {
+            npm = chunk_pieces(cs_s, chunk);
+            issue(cs_s, ro, chunk, npm);
         }
-        if (tid == 64 % T) { // row constants of select_variables, off thread 0
-            misc_s[MS_BMIN] = c_bmin;
-            misc_s[MS_BMAX] = c_bmax;
-            misc_s[MS_BNEG] = c_bneg;
-            *(double*)(misc_s + MS_RBYTES) = c_rbytes;
-            // slots of the selection's LDS-atomic reductions (part_s[64..])
-            part_s[64] = 0ull;  // largest key
-            part_s[65] = 0ull;  // largest N key
-            part_s[66] = ~0ull; // smallest S key
-            part_s[67] = 0ull;  // counts: N in the high half, Z in the low half
-            part_s[68] = 0ull;  // tie flag
-        }
-        if (it + 1 < nrows)
-            fetch_consts(k_next);
-        BXH_STAMP(1);
-        __syncthreads();
-        if (MW)
-            for (int l = tid; l < ro; l += T)
-                loc_s[oidx_s[l]] = (short)l;
         BXH_STAMP(0);
 
         // ---- decrease_preference + compute_reduced_costs ------------------
-        // Wave-private pipeline, no workgroup barrier inside.  Columns are
-        // stored padded to 16 entries (128 bytes of P), so a column is a
-        // whole number of 16-entry pieces: an 8-lane group loads one piece
-        // per instruction (16 B of P + 8 B of row indices per lane = exactly
-        // one cache line of P), all pieces of a 16-column chunk in flight
-        // together and those of the wave's next chunk issued before the sums
-        // of this one.  The pieces are staged in the wave's LDS slots; lanes
-        // 0-15 then add the P entries and lanes 16-31 the pi entries of one
-        // column each, strictly in CSC order
+        // Wave-private pipeline, no workgroup barrier inside.  The pieces of
+        // a 16-column chunk are staged in the wave's LDS slots, those of the
+        // wave's next chunk issued before the sums of this one; lanes 0-15
+        // then add the P entries and lanes 16-31 the pi entries of one column
+        // each, strictly in CSC order
         // (itm-solver-inequalities-01.cpp:173-188); padding entries are +0.0
         // / pi_s[m] == +0.0 and leave the sums bit-identical.
         {
-            constexpr int CW = 8 * LR; // columns of a wave's chunk
-            const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
-            const int g8 = lane >> 3;
-            Float* wst_p = stg_p + wave * (CW * SP);
-            unsigned short* wst_i = stg_i + wave * (CW * SI);
-            Float2 regP[LR][NP];
-            unsigned regI[LR][NP]; // two 16-bit row indices per lane and piece
-            const char* Pb = reinterpret_cast<const char*>(P);
-            const char* Ib = reinterpret_cast<const char*>(crow);
-            auto issue = [&](int chunk) {
-#pragma unroll
-                for (int h = 0; h < LR; ++h) {
-                    const int t = chunk * CW + h * 8 + g8;
-                    if (t < ro) {
-                        const int2 cs = cs_s[t];
-                        const unsigned last = (unsigned)(cs.y >> 4) - 1u;
-                        const unsigned q0 = (unsigned)cs.x + 2u * (unsigned)l8;
-#pragma unroll
-                        for (int b = 0; b < NP; ++b) {
-                            // pieces past the column's end re-read its last
-                            // piece (a cache hit): no branch per load and no
-                            // use of the values here, so all stay in flight;
-                            // 32-bit offsets from a uniform base
-                            const unsigned q = q0 + (min((unsigned)b, last) << 4);
-                            regP[h][b] = *reinterpret_cast<const Float2*>(
-                              Pb + q * (unsigned)sizeof(Float));
-                            regI[h][b] =
-                              *reinterpret_cast<const unsigned*>(Ib + q * 2u);
-                        }
-                    }
-                }
-            };
-            const int nchunks = (ro + CW - 1) / CW;
-            int chunk = wave;
-            if (chunk < nchunks)
-                issue(chunk);
             for (; chunk < nchunks; chunk += nwaves) {
 #pragma unroll
                 for (int h = 0; h < LR; ++h) {
                     const int t = chunk * CW + h * 8 + g8;
                     if (t < ro) {
-                        // every piece is stored; the adders only read the
-                        // column's own (padded) length
+                        // every loaded piece is stored; the adders only read
+                        // the column's own (padded) length
                         Float* dp = wst_p + (h * 8 + g8) * SP + 2 * l8;
                         unsigned short* di = wst_i + (h * 8 + g8) * SI + 2 * l8;
 #pragma unroll
                         for (int b = 0; b < NP; ++b) {
-                            *reinterpret_cast<Float2*>(dp + b * 16) = regP[h][b];
-                            *reinterpret_cast<unsigned*>(di + b * 16) = regI[h][b];
+                            if (b < npm) {
+                                *reinterpret_cast<Float2*>(dp + b * 16) = regP[h][b];
+                                *reinterpret_cast<unsigned*>(di + b * 16) = regI[h][b];
+                            }
                         }
                     }
                 }
@@ -1366,8 +1396,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 BXH_STAMP(12);
-                if (chunk + nwaves < nchunks)
-                    issue(chunk + nwaves);
+                if (chunk + nwaves < nchunks) {
+                    npm = chunk_pieces(cs_s, chunk + nwaves);
+                    issue(cs_s, ro, chunk + nwaves, npm);
+                }
                 BXH_STAMP(13);
 
                 if (lane < 2 * CW) {
@@ -1376,10 +1408,12 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     const int t = chunk * CW + u;
                     if (t < ro) {
                         const int2 cs = cs_s[t];
-                        const int cpad = cs.y;
+                        const int cpad = cs.y & 0xffff;
                         if (!is_pi) { // P[e] *= theta for this row's entry
                             Float* pk = wst_p + u * SP + (pe_s[t] - cs.x);
-                            *pk = *pk * theta; // (stored to HBM by affect)
+                            const Float dec = *pk * theta; // (stored to HBM by affect)
+                            *pk = dec;
+                            pown_s[t] = dec;
                         }
                         const Float2* sp2 =
                           reinterpret_cast<const Float2*>(wst_p + u * SP);
@@ -1436,7 +1470,6 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         BXH_STAMP(15);
         __syncthreads();
         BXH_STAMP(2);
-
         // Row exchange among the owners: every reduced cost travels as two
         // naturally aligned 8-byte granules {32 value bits, 32-bit tag}, each
         // written by ONE write-through store and read with L1-bypassing loads
@@ -1450,11 +1483,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         for (int l = tid; l < ro; l += T) {
             const int idx = MW ? oidx_s[l] : l; // position in the whole row
             const int j = col_s[l];
-            Float v = cost[j] - spi_s[l] - sp_s[l];
+            Float v = cost_s[l] - spi_s[l] - sp_s[l];
             if (PM1 && pb.fac_csr[rs + idx] < 0)
                 v = -v;
             if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
-                v += obj_amp * (PM1 ? cost[j] : cost[idx]);
+                v += obj_amp * (PM1 ? cost_s[l] : cost[idx]);
             if (MW) {
                 const unsigned long long bits =
                   (unsigned long long)__double_as_longlong((double)v);
@@ -1466,6 +1499,37 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 val_s[idx] = v;
             }
         }
+        // ---- the next row's descriptor -> LDS, the one after it -> registers
+        // (between the owners' stores and the polling of the partners' values:
+        // no younger loads are in flight here, so waiting for these registers
+        // waits for nothing else) -------------------------------------
+        if (it + 1 < nrows) {
+            store_desc(x1, cur ^ 1);
+            if (it + 2 < nrows) {
+                fetch_desc(x2);
+                if (it + 3 < nrows) {
+                    x3 = row_extent(k3);
+                    if (it + 4 < nrows)
+                        k4 = row_at(it + 4);
+                }
+            }
+        }
+        BXH_STAMP(11);
+        if (tid == 64 % T) { // row constants of select_variables, off thread 0
+            misc_s[MS_BMIN] = c_bmin;
+            misc_s[MS_BMAX] = c_bmax;
+            misc_s[MS_BNEG] = c_bneg;
+            *(double*)(misc_s + MS_RBYTES) = c_rbytes;
+            // slots of the selection's LDS-atomic reductions (part_s[64..])
+            part_s[64] = 0ull;  // largest key
+            part_s[65] = 0ull;  // largest N key
+            part_s[66] = ~0ull; // smallest S key
+            part_s[67] = 0ull;  // counts: N in the high half, Z in the low half
+            part_s[68] = 0ull;  // tie flag
+        }
+        if (it + 1 < nrows)
+            fetch_consts(x1.k);
+        BXH_STAMP(1);
         if (MW) {
             for (int idx = tid; idx < r; idx += T) {
                 unsigned long long lo, hi;
@@ -1495,6 +1559,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         for (int i = tid; i < 2 * n2max; i += T)
             htab[i] = 0ull;
         __syncthreads();
+        if (it + 1 < nrows)
+            fill_loc(x1, cur ^ 1);
         BXH_STAMP(3);
 
         // ---- selection without sorting (rows with no two equal reduced
@@ -1725,7 +1791,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     bool up = mode == 1 || (mode == 2 && key <= thr);
                     if (PM1 && pb.fac_csr[rs + idx] < 0)
                         up = !up;
-                    const Float p = P[pe] * theta;
+                    const Float p = pown_s[l]; // P[pe] * theta
                     if (up) {
                         atomicOr(&x_s[j >> 5], 1u << (j & 31));
                         P[pe] = p + d;
@@ -1854,7 +1920,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 bool up = i <= sel;
                 if (PM1 && pb.fac_csr[rs + idx] < 0)
                     up = !up;
-                const Float p = P[pe] * theta;
+                const Float p = pown_s[l]; // P[pe] * theta
                 if (up) {
                     atomicOr(&x_s[j >> 5], 1u << (j & 31));
                     P[pe] = p + d;

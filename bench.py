@@ -136,6 +136,23 @@ def cpu_baseline(inst, params, float_type, seconds, threads):
     }
 
 
+def pmc_traffic(workload, float_type):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this very
+    workload (profiles/r*/pmc_traffic.json, made by tools/pmc_traffic.py); the
+    counters cannot be read from inside the process, so any other workload or
+    float type reports null."""
+    best = None
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for rnd in sorted(os.listdir(root)) if os.path.isdir(root) else []:
+        path = os.path.join(root, rnd, "pmc_traffic.json")
+        if os.path.isfile(path):
+            with open(path) as f:
+                rec = json.load(f)
+            if rec.get("workload") == workload and float_type == 1:
+                best = rec["traffic_bytes_per_launch"]
+    return best
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -226,6 +243,8 @@ def main():
         per_launch_bytes = alg / max(launches, 1)
         per_launch_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        workload = (f"{inst.name}: scpnrh1-shaped SCP {inst.m}x{inst.n} nnz={inst.nnz}, "
+                    f"inequalities-01, {args.batch} restarts/GPU, {args.cost_kind} costs")
         out = {
             "metric": "row-updates/sec (itm inner loop)",
             "value": rows_all / dt_max,
@@ -240,8 +259,7 @@ def main():
             "dtype": "f64" if float_type else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{inst.name}: scpnrh1-shaped SCP {inst.m}x{inst.n} nnz={inst.nnz}, "
-                            f"inequalities-01, {args.batch} restarts/GPU, {args.cost_kind} costs",
+                "workload": workload,
                 "restarts_per_gpu": args.batch,
                 "row_updates": rows_all,
                 "best_objective": None if not np.isfinite(best_t.item()) else float(best_t.item()),
@@ -252,7 +270,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(workload, float_type),
                 "kernel": "bxh::sweep_kernel",
                 "launches": int(launches),
                 "avg_launch_ms": kernel_ms / max(launches, 1),

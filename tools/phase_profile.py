@@ -24,9 +24,10 @@ cost = normalize_costs(inst.dense_costs(), 4, float_type)
 delta = compute_delta(cost, 0.5, float_type)
 dev = _ffi.DeviceBatch(inst, cost, batch, float_type=float_type)
 x0 = np.zeros((batch, dev.nwords), np.uint64)
-names = ["desc", "fast:select", "rc:final-barrier", "combine", "sort:other|fast:merge-partials", "thread0|fast:scan+keys", "affect", "violated",
-         "sort:wave-bitonic|fast:keys+hash+reduce", "sort:barrier1|fast:barrier", "sort:rank-search|fast:thread0", "sort:barrier2",
-         "rc:wait+stage", "rc:issue", "rc:sum", "rc:tail"]
+names = ["rc:first-issue", "consts", "rc:final-barrier", "combine+exchange", "sort:other|fast:merge-partials",
+         "thread0|fast:scan+keys", "affect", "violated", "sort:wave-bitonic|fast:keys+hash+reduce",
+         "sort:barrier1|fast:barrier", "sort:rank-search|fast:d", "desc:next-row", "rc:wait+stage", "rc:issue-next",
+         "rc:sum", "rc:tail"]
 for step in range(4):
     dev.set_x_all(x0)
     dev.order_init(0, sync=False)
