@@ -386,6 +386,8 @@ bxh_create(const bxh_problem* pb,
             const int g = std::atoi(eg);
             if ((g == 1 || g == 2 || g == 4) && batch * g <= cus)
                 groups = g;
+            else if (g == 8 && batch * g <= 2 * cus) // two workgroups per CU
+                groups = g;
         }
     }
     h->groups = groups;
@@ -595,11 +597,18 @@ bxh_create(const bxh_problem* pb,
     if (v2_ok) {
         const int np = cmax <= 64 ? 4 : (cmax <= 80 ? 5 : (cmax <= 96 ? 6 : 8));
         // 16 staging slots per wave; as many waves (up to 8) as LDS allows
-        for (int t = 512; t >= 128; t >>= 1) {
+        int tmax = 512, lds_cap = lds_limit;
+        if (const char* et = std::getenv("BXH_THREADS"))
+            tmax = std::max(128, std::min(512, std::atoi(et)));
+        if (groups == 8) { // two resident workgroups share a CU's LDS
+            tmax = std::min(tmax, 256);
+            lds_cap = lds_limit / 2;
+        }
+        for (int t = tmax; t >= 128; t >>= 1) {
             const bxh::LdsPlan2 lp2 = bxh::lds_plan2(m, h->nwords, rmax, romax,
                                                      static_cast<int>(h->fsize),
                                                      (t / 64) * 16, np, groups > 1);
-            if (lp2.total <= lds_limit) {
+            if (lp2.total <= lds_cap) {
                 h->version = 2;
                 h->nb = np;
                 h->threads = t;
@@ -608,6 +617,9 @@ bxh_create(const bxh_problem* pb,
             }
         }
     }
+    if (std::getenv("BXH_DEBUG"))
+        std::fprintf(stderr, "bxh: kernel v%d threads=%d lds=%zu np=%d groups=%d\n", h->version,
+                     h->threads, h->lds_bytes, h->nb, groups);
     if (h->version != 2 && groups > 1)
         return fail(BXH_ERR_UNSUPPORTED, "instance does not fit the staged kernel's LDS plan");
 

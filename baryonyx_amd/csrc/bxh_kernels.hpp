@@ -1341,6 +1341,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         }
     };
 
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(st.xbuf + (size_t)inst * 2 * pb.rmax * 2), 0, MW ? 2 * pb.rmax * 16 : 0, 0x00020000);
+
     for (int it = 0; it < nrows; ++it, x0 = x1, x1 = x2, x2 = x3, k3 = k4) {
         const int cur = it & 1;
         const int k = x0.k;
@@ -1471,15 +1475,15 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         __syncthreads();
         BXH_STAMP(2);
         // Row exchange among the owners: every reduced cost travels as two
-        // naturally aligned 8-byte granules {32 value bits, 32-bit tag}, each
-        // written by ONE write-through store and read with L1-bypassing loads
-        // until its tag is the current (launch, row) number -- no counter, no
-        // barrier, one L2 round trip.  Two slots alternate: a workgroup can
-        // only be one row ahead of its partners (it needs their values).
-        unsigned long long* xb =
-          MW ? st.xbuf + (((size_t)inst * 2 + (it & 1)) * pb.rmax) * 2 : nullptr;
-        const unsigned long long tag =
-          (unsigned long long)(((a.epoch & 0x1ffffu) << 15) | (unsigned)(it + 1)) << 32;
+        // naturally aligned 8-byte granules {32 value bits, 32-bit tag}, both
+        // written by ONE write-through 16-byte store and read by one
+        // L1-bypassing 16-byte load until each granule's tag is the current
+        // (launch, row) number -- each granule validates itself, so no
+        // counter, no barrier and no ordering is needed.  Two slots alternate:
+        // a workgroup can only be one row ahead of its partners (it needs
+        // their values).
+        const unsigned xoff = (unsigned)(it & 1) * (unsigned)pb.rmax * 16u;
+        const unsigned tag32 = ((a.epoch & 0x1ffffu) << 15) | (unsigned)(it + 1);
         for (int l = tid; l < ro; l += T) {
             const int idx = MW ? oidx_s[l] : l; // position in the whole row
             const int j = col_s[l];
@@ -1491,10 +1495,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             if (MW) {
                 const unsigned long long bits =
                   (unsigned long long)__double_as_longlong((double)v);
-                __hip_atomic_store(&xb[2 * idx], (bits & 0xffffffffull) | tag,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&xb[2 * idx + 1], (bits >> 32) | tag,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const v4u g = { (unsigned)bits, tag32, (unsigned)(bits >> 32), tag32 };
+                // both granules by one write-through (sc1) 16-byte store
+                __builtin_amdgcn_raw_buffer_store_b128(g, xrsrc, xoff + (unsigned)idx * 16u, 0, 16);
             } else {
                 val_s[idx] = v;
             }
@@ -1532,12 +1535,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         BXH_STAMP(1);
         if (MW) {
             for (int idx = tid; idx < r; idx += T) {
-                unsigned long long lo, hi;
+                v4u g;
                 long spins = 0;
-                for (;;) {
-                    lo = __hip_atomic_load(&xb[2 * idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hi = __hip_atomic_load(&xb[2 * idx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((lo & 0xffffffff00000000ull) == tag && (hi & 0xffffffff00000000ull) == tag)
+                for (;;) { // L1-bypassing (sc1) 16-byte load of both granules
+                    g = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + (unsigned)idx * 16u, 0, 16);
+                    if (g.y == tag32 && g.w == tag32)
                         break;
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > 2000000L) { // a partner is missing: give up loudly
@@ -1545,7 +1547,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         break;
                     }
                 }
-                const unsigned long long bits = (lo & 0xffffffffull) | (hi << 32);
+                const unsigned long long bits = (unsigned long long)g.x | ((unsigned long long)g.z << 32);
                 val_s[idx] = (Float)__longlong_as_double((long long)bits);
             }
         }
