@@ -313,6 +313,95 @@ bcast_first_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Wave-wide minima of 32-bit values on the DPP path only (no LDS): four
+// butterfly steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31
+// carry the row results up to row 3, and lane 63 is read back as a wave-uniform
+// scalar.  v_min_u32_dpp folds the lane exchange into the min.  A DPP source
+// written by the previous VALU instruction needs two wait states: the variant
+// with four independent chains interleaves them (three instructions between
+// two steps of one chain), the single chain pays an s_nop per step.  Every
+// lane of the wave must be active.
+#define BXH_DPP1(R, CTRL) "v_min_u32_dpp " R ", " R ", " R " " CTRL "\n"
+#define BXH_DPP4(CTRL) BXH_DPP1("%0", CTRL) BXH_DPP1("%1", CTRL) BXH_DPP1("%2", CTRL) BXH_DPP1("%3", CTRL)
+__device__ inline void
+wave_umin32x4(unsigned& a, unsigned& b, unsigned& c, unsigned& d)
+{
+    asm volatile("s_nop 4\n" BXH_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                   BXH_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                     BXH_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf")
+                       BXH_DPP4("row_mirror row_mask:0xf bank_mask:0xf")
+                         BXH_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                           BXH_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    a = (unsigned)__builtin_amdgcn_readlane((int)a, 63);
+    b = (unsigned)__builtin_amdgcn_readlane((int)b, 63);
+    c = (unsigned)__builtin_amdgcn_readlane((int)c, 63);
+    d = (unsigned)__builtin_amdgcn_readlane((int)d, 63);
+}
+
+__device__ inline unsigned
+wave_umin32(unsigned a)
+{
+    asm volatile("s_nop 4\n" BXH_DPP1("%0", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") "s_nop 1\n"
+                   BXH_DPP1("%0", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") "s_nop 1\n"
+                     BXH_DPP1("%0", "row_half_mirror row_mask:0xf bank_mask:0xf") "s_nop 1\n"
+                       BXH_DPP1("%0", "row_mirror row_mask:0xf bank_mask:0xf") "s_nop 1\n"
+                         BXH_DPP1("%0", "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 1\n"
+                           BXH_DPP1("%0", "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n"
+                 : "+v"(a));
+    return (unsigned)__builtin_amdgcn_readlane((int)a, 63);
+}
+#undef BXH_DPP4
+#undef BXH_DPP1
+
+// 64-bit minima: the high words first, then the low words of the lanes whose
+// high word is the minimum.  Results are wave-uniform.
+__device__ inline void
+wave_umin64x4(unsigned long long& a, unsigned long long& b, unsigned long long& c,
+              unsigned long long& d)
+{
+    unsigned ah = (unsigned)(a >> 32), bh = (unsigned)(b >> 32), ch = (unsigned)(c >> 32),
+             dh = (unsigned)(d >> 32);
+    unsigned mah = ah, mbh = bh, mch = ch, mdh = dh;
+    wave_umin32x4(mah, mbh, mch, mdh);
+    unsigned al = ah == mah ? (unsigned)a : ~0u, bl = bh == mbh ? (unsigned)b : ~0u,
+             cl = ch == mch ? (unsigned)c : ~0u, dl = dh == mdh ? (unsigned)d : ~0u;
+    wave_umin32x4(al, bl, cl, dl);
+    a = ((unsigned long long)mah << 32) | al;
+    b = ((unsigned long long)mbh << 32) | bl;
+    c = ((unsigned long long)mch << 32) | cl;
+    d = ((unsigned long long)mdh << 32) | dl;
+}
+
+__device__ inline unsigned long long
+wave_umin64(unsigned long long a)
+{
+    const unsigned ah = (unsigned)(a >> 32);
+    const unsigned mah = wave_umin32(ah);
+    const unsigned mal = wave_umin32(ah == mah ? (unsigned)a : ~0u);
+    return ((unsigned long long)mah << 32) | mal;
+}
+
+__device__ inline unsigned long long
+uniform_u64(unsigned long long v) // a value every lane holds -> scalar registers
+{
+    return bcast_first_u64(v);
+}
+
+// Tie filter: one bit per hashed key in an LDS bitmap of 2^16 bits.  A key whose
+// bit was already set MAY equal an earlier key of the row; two equal keys
+// always leave the later one flagged.
+__device__ inline bool
+filter_insert(unsigned* bitmap, unsigned long long key)
+{
+    unsigned x = (unsigned)(key >> 32) * 0x9E3779B1u + (unsigned)key * 0x85EBCA77u;
+    x ^= x >> 15;
+    x *= 0xC2B2AE3Du;
+    const unsigned i = x >> 16;
+    const unsigned bit = 1u << (i & 31);
+    return (atomicOr(&bitmap[i >> 5], bit) & bit) != 0u;
+}
+
 // Open-addressing insert of a non-zero key; returns true when the key was
 // already there (two equal reduced costs in the row).
 __device__ inline bool
@@ -1529,6 +1618,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             part_s[66] = ~0ull; // smallest S key
             part_s[67] = 0ull;  // counts: N in the high half, Z in the low half
             part_s[68] = 0ull;  // tie flag
+            part_s[69] = ~0ull; // smallest key
         }
         if (it + 1 < nrows)
             fetch_consts(x1.k);
@@ -1556,10 +1646,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             misc_s[MS_TIE] = 0;
             misc_s[MS_FAST] = 0;
         }
-        // the tie-detection table shares LDS with the staging slots: clear
-        const unsigned hmask = (unsigned)(2 * n2max - 1);
-        for (int i = tid; i < 2 * n2max; i += T)
-            htab[i] = 0ull;
+        // the tie filter's bitmap (2^16 bits) shares LDS with the staging
+        // slots: clear
+        for (int i = tid; i < 512; i += T)
+            reinterpret_cast<uint4*>(htab)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         if (it + 1 < nrows)
             fill_loc(x1, cur ^ 1);
@@ -1583,60 +1673,78 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         unsigned long long mykey[2] = { 0ull, 0ull };
         if (r <= 2 * T && r >= 2) {
             const unsigned long long K0 = order_key<Float>((Float)0, maximize);
-            unsigned long long mn1 = ~0ull, mn2 = ~0ull, mx1 = 0ull, mxN = 0ull, mnS = ~0ull;
+            // per lane: A smallest key, A2 second smallest, B ~largest, C
+            // ~largest of class N, D smallest of class S (maxima as minima of
+            // the complement: one kind of reduction)
+            unsigned long long A = ~0ull, A2 = ~0ull, B = ~0ull, C = ~0ull, D = ~0ull;
             int cN = 0, cZ = 0;
-            bool tie = false;
+            bool flagged[2] = { false, false };
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int e = tid + s2 * T;
                 const bool have = e < r;
-                unsigned long long k = 0ull;
+                unsigned long long k = ~0ull;
                 if (have) {
                     k = order_key<Float>(val_s[e], maximize);
-                    tie = hash_insert(htab, hmask, k) || tie;
+                    flagged[s2] = filter_insert(reinterpret_cast<unsigned*>(htab), k);
                 }
-                mykey[s2] = k;
+                mykey[s2] = have ? k : 0ull;
                 const bool isN = have && k < K0, isZ = have && k == K0;
                 const bool isS = have && k > K0;
                 cN += __popcll(__ballot(isN));
                 cZ += __popcll(__ballot(isZ));
-                if (have) {
-                    if (k < mn1) {
-                        mn2 = mn1;
-                        mn1 = k;
-                    } else if (k < mn2) {
-                        mn2 = k;
-                    }
-                    mx1 = k > mx1 ? k : mx1;
+                if (s2 == 0) {
+                    A = k;
+                    B = have ? ~k : ~0ull;
+                } else {
+                    A2 = umax64(A, k);
+                    A = umin64(A, k);
+                    B = umin64(B, have ? ~k : ~0ull);
                 }
-                if (isN)
-                    mxN = k > mxN ? k : mxN;
-                if (isS)
-                    mnS = k < mnS ? k : mnS;
+                C = umin64(C, isN ? ~k : ~0ull);
+                D = umin64(D, isS ? k : ~0ull);
             }
-            // wave reductions; the second smallest is the minimum of what is
-            // left once the wave's smallest key is known (keys are distinct
-            // unless the row has a tie, which takes the sort path anyway)
-            {
-                const unsigned long long own1 = mn1, own2 = mn2;
-                mn1 = wave_min_u64(mn1);
-                mn2 = own1 == mn1 ? own2 : own1;
-                mn2 = wave_min_u64(mn2);
+            // a flagged key is looked up in the whole row by its wave (rare:
+            // the bitmap is 128 times larger than the row)
+            bool wtie = false;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                unsigned long long pending = __ballot(flagged[s2]);
+                while (pending) {
+                    const int src = __ffsll((long long)pending) - 1;
+                    pending &= pending - 1;
+                    const unsigned long long fk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(
+                                                     (int)(unsigned)(mykey[s2] >> 32), src)
+                                                   << 32) |
+                                                  (unsigned)__builtin_amdgcn_readlane(
+                                                    (int)(unsigned)mykey[s2], src);
+                    int same = 0; // uniform: ballots over 64 entries at a time
+                    for (int e0 = 0; e0 < r; e0 += 64) {
+                        const int e = e0 + (tid & 63);
+                        const bool eq = e < r && order_key<Float>(val_s[e], maximize) == fk;
+                        same += __popcll(__ballot(eq));
+                    }
+                    if (same >= 2)
+                        wtie = true;
+                }
             }
-            BXH_ROW_REDUCE(mx1, umax64);
-            BXH_ROW_REDUCE(mxN, umax64);
-            BXH_ROW_REDUCE(mnS, umin64);
-            const bool wtie = __ballot(tie) != 0ull;
+            // wave reductions (uniform results); the second smallest is the
+            // minimum of what is left once the wave's smallest key is known
+            // (keys are distinct unless the row has a tie, which takes the
+            // sort path anyway)
+            const unsigned long long ownA = A;
+            wave_umin64x4(A, B, C, D);
+            unsigned long long E = ownA == A ? A2 : ownA;
+            E = wave_umin64(E);
             {
                 const int wave = tid >> 6, lane = tid & 63;
-                if ((lane & 15) == 0) { // the four row leaders of the wave
-                    atomicMax(&part_s[64], mx1);
-                    atomicMax(&part_s[65], mxN);
-                    atomicMin(&part_s[66], mnS);
-                }
                 if (lane == 0) {
-                    part_s[wave * 2] = mn1;
-                    part_s[wave * 2 + 1] = mn2;
+                    atomicMax(&part_s[64], ~B); // largest key
+                    atomicMax(&part_s[65], ~C); // largest N key
+                    atomicMin(&part_s[66], D);  // smallest S key
+                    atomicMin(&part_s[69], A);  // smallest key
+                    part_s[wave * 2] = A;
+                    part_s[wave * 2 + 1] = E;
                     atomicAdd(&part_s[67], ((unsigned long long)(unsigned)cN << 32) | (unsigned)cZ);
                     if (wtie)
                         atomicOr(&part_s[68], 1ull);
@@ -1645,23 +1753,29 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             BXH_STAMP(8);
             __syncthreads();
             BXH_STAMP(9);
-            // Every wave merges the per-wave partials with its first lanes and
-            // then runs the same, wave-uniform selection logic: no second
-            // barrier, no broadcast through LDS.  All threads keep identical
-            // copies of the engine state (re-read after a sort-path row).
+            // Every wave then runs the same, wave-uniform selection logic on
+            // scalar registers: no second barrier, no broadcast through LDS.
+            // All threads keep identical copies of the engine state (re-read
+            // after a sort-path row).
             {
                 const int nw = T >> 6;
-                // two smallest keys: merge of the waves' sorted pairs
-                unsigned long long g1 = ~0ull, g2 = ~0ull;
-                for (int w = 0; w < nw; ++w) {
-                    const unsigned long long a1 = part_s[w * 2], a2 = part_s[w * 2 + 1];
-                    const unsigned long long lo1 = umin64(a1, g1), hi1 = umax64(a1, g1);
-                    g2 = umin64(hi1, umin64(a2, g2));
-                    g1 = lo1;
-                }
-                const unsigned long long gx = part_s[64], gxN = part_s[65], gnS = part_s[66];
-                const unsigned long long cnt = part_s[67];
-                const unsigned long long tflag = part_s[68];
+                const unsigned long long g1 = uniform_u64(part_s[69]);
+                const unsigned long long gx = uniform_u64(part_s[64]), gxN = uniform_u64(part_s[65]),
+                                         gnS = uniform_u64(part_s[66]);
+                // second smallest key, only where it is asked for: the minimum
+                // over the waves of "second smallest of the wave that holds
+                // g1, smallest of the others"
+                auto second_smallest = [&]() -> unsigned long long {
+                    const int lane = tid & 63;
+                    unsigned long long cnd = ~0ull;
+                    if (lane < nw) {
+                        const unsigned long long a1 = part_s[lane * 2], a2 = part_s[lane * 2 + 1];
+                        cnd = a1 == g1 ? a2 : a1;
+                    }
+                    return wave_umin64(cnd);
+                };
+                const unsigned long long cnt = uniform_u64(part_s[67]);
+                const unsigned long long tflag = uniform_u64(part_s[68]);
                 const int nN = (int)(cnt >> 32), nZ = (int)(cnt & 0xffffffffu);
                 const bool anytie = tflag != 0ull;
                 BXH_STAMP(4);
@@ -1713,7 +1827,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         if (rank == 0)
                             return g1;
                         if (rank == 1)
-                            return g2;
+                            return second_smallest();
                         if (rank == r - 1)
                             return gx;
                         if (nN > 0 && rank == nN - 1)
