@@ -32,7 +32,7 @@ SYMBOLS = [
     "bxh_last_error", "bxh_create", "bxh_destroy", "bxh_set_stream", "bxh_batch",
     "bxh_nwords", "bxh_rmax", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_set_pi", "bxh_get_pi",
     "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset",
-    "bxh_order_init", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
+    "bxh_order_create", "bxh_order_init", "bxh_order_init_masked", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
     "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time",
 ]
 
@@ -141,6 +141,8 @@ def lib():
         L.bxh_get_rng.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
         L.bxh_reset.argtypes = [C.c_void_p, C.c_int]
         L.bxh_order_init.argtypes = [C.c_void_p, C.c_int, i32p]
+        L.bxh_order_create.argtypes = [C.c_void_p, C.c_int]
+        L.bxh_order_init_masked.argtypes = [C.c_void_p, C.c_int, u8p, i32p]
         L.bxh_get_violated.argtypes = [C.c_void_p, C.c_int, i32p, i32p]
         L.bxh_sweep.argtypes = [C.c_void_p, C.POINTER(BxhSweepArgs), C.c_void_p]
         L.bxh_sweep_async.argtypes = [C.c_void_p, C.POINTER(BxhSweepArgs)]
@@ -265,16 +267,22 @@ class DeviceBatch:
     def reset(self, i):
         _check(self.L.bxh_reset(self.h, i))
 
-    def order_init(self, order=0, sync=True):
+    def order_create(self, order):
+        """compute_order's constructor for every instance."""
+        _check(self.L.bxh_order_create(self.h, int(order)))
+
+    def order_init(self, order=0, sync=True, active=None):
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        actp = _p(act, u8p) if act is not None else None
         if not sync:
-            _check(self.L.bxh_order_init(self.h, order, None))
+            _check(self.L.bxh_order_init_masked(self.h, order, actp, None))
             return None
         rem = np.zeros(self.batch, np.int32)
-        _check(self.L.bxh_order_init(self.h, order, _p(rem, i32p)))
+        _check(self.L.bxh_order_init_masked(self.h, order, actp, _p(rem, i32p)))
         return rem
 
     def violated(self, i):
-        rows = np.zeros(self.inst.m, np.int32)
+        rows = np.zeros(max(self.inst.m, self.inst.n), np.int32)
         cnt = C.c_int32()
         _check(self.L.bxh_get_violated(self.h, i, _p(rows, i32p), C.byref(cnt)))
         return rows[: cnt.value].copy()

@@ -107,6 +107,16 @@ struct bxh_handle_s
     DevBuf<unsigned char> P, pi, rstale;
     DevBuf<unsigned> x;
     DevBuf<int> vlist, vcount;
+    // compute_order (itm-common.hpp:627-915): one state per instance
+    int lcap = 0;              // capacity of the row lists: max(m, n)
+    int policy = -1;           // constraint_order given to the constructor, -1: none yet
+    bool use_cycle = false;
+    std::vector<int> ostate;   // current order of every instance (0..7)
+    DevBuf<int> order_b;       // the same, on the device
+    int* h_order = nullptr;    // pinned staging
+    DevBuf<int2> mlist, mtmp;
+    DevBuf<int> mcount, mrun, slist, vamt, sid;
+    DevBuf<unsigned long long> skey;
     DevBuf<signed char> vflag;
     DevBuf<bxh::DevStatus> status;
     DevBuf<unsigned long long> prof;
@@ -134,6 +144,8 @@ struct bxh_handle_s
             (void)hipHostFree(h_kappa);
         if (h_active)
             (void)hipHostFree(h_active);
+        if (h_order)
+            (void)hipHostFree(h_order);
         for (auto& ev : events) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
@@ -689,7 +701,9 @@ bxh_create(const bxh_problem* pb,
     const size_t B = static_cast<size_t>(batch);
     const size_t GG = static_cast<size_t>(groups);
     HIP_TRY(h->P.alloc(B * GG * nnzp * h->fsize));
-    HIP_TRY(h->vwork.alloc(B * GG * m));
+    const size_t LC = static_cast<size_t>(std::max(m, n));
+    h->lcap = static_cast<int>(LC);
+    HIP_TRY(h->vwork.alloc(B * GG * LC));
     HIP_TRY(h->vpart.alloc(B * GG * m));
     HIP_TRY(h->xbuf.alloc(B * 2 * rmax * 2));
     HIP_TRY(hipMemset(h->xbuf.p, 0, B * 2 * rmax * 2 * sizeof(unsigned long long)));
@@ -698,7 +712,25 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->pi.alloc(B * m * h->fsize));
     HIP_TRY(h->rstale.alloc(B * (rmax + 1) * h->fsize));
     HIP_TRY(h->x.alloc(B * 2 * h->nwords));
-    HIP_TRY(h->vlist.alloc(B * m));
+    HIP_TRY(h->vlist.alloc(B * LC));
+    {
+        const size_t n2cap = static_cast<size_t>(bxh::next_pow2(static_cast<int>(std::max<size_t>(LC, 2))));
+        HIP_TRY(h->mlist.alloc(B * LC));
+        HIP_TRY(h->mtmp.alloc(B * LC));
+        HIP_TRY(h->mcount.alloc(B));
+        HIP_TRY(h->mrun.alloc(B * LC));
+        HIP_TRY(h->slist.alloc(B * LC));
+        HIP_TRY(h->vamt.alloc(B * m));
+        HIP_TRY(h->skey.alloc(B * n2cap));
+        HIP_TRY(h->sid.alloc(B * n2cap));
+        HIP_TRY(h->order_b.alloc(B));
+        HIP_TRY(hipMemset(h->order_b.p, 0, B * sizeof(int)));
+        HIP_TRY(hipMemset(h->mlist.p, 0, B * LC * sizeof(int2)));
+        HIP_TRY(hipMemset(h->mcount.p, 0, B * sizeof(int)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_order), B * sizeof(int),
+                              hipHostMallocDefault));
+        h->ostate.assign(B, 0);
+    }
     HIP_TRY(h->vcount.alloc(B));
     HIP_TRY(h->vflag.alloc(B * GG * m));
     HIP_TRY(h->status.alloc(B));
@@ -825,6 +857,15 @@ bxh_create(const bxh_problem* pb,
     ds.status = h->status.p;
     ds.prof = h->prof.p;
     ds.vwork = h->vwork.p;
+    ds.lcap = h->lcap;
+    ds.mlist = h->mlist.p;
+    ds.mcount = h->mcount.p;
+    ds.mrun = h->mrun.p;
+    ds.mtmp = h->mtmp.p;
+    ds.slist = h->slist.p;
+    ds.vamt = h->vamt.p;
+    ds.skey = h->skey.p;
+    ds.sid = h->sid.p;
     ds.vpart = h->vpart.p;
     ds.xbuf = h->xbuf.p;
     ds.cnt = h->cnt.p;
@@ -993,16 +1034,54 @@ bxh_reset(bxh_handle h, int inst)
     return BXH_OK;
 }
 
+// compute_order's constructor (itm-common.hpp:640-658): `cycle` starts as
+// `none`; both lists are sized with the number of variables, m_order with
+// value-initialised pairs (which a `cycle` run meets before they are first
+// computed).
 int
-bxh_order_init(bxh_handle h, int order, int32_t* remaining)
+bxh_order_create(bxh_handle h, int order)
 {
     if (!h)
         return fail(BXH_ERR_INVALID, "null handle");
-    if (order < BXH_ORDER_NONE || order > BXH_ORDER_RANDOM_SORTING)
+    if (order < BXH_ORDER_NONE || order > BXH_ORDER_CYCLE)
+        return fail(BXH_ERR_INVALID, "unknown constraint order");
+    if ((order == BXH_ORDER_PI_SIGN_CHANGE || order == BXH_ORDER_CYCLE) && h->n > h->m)
         return fail(BXH_ERR_UNSUPPORTED,
-                    "only none / reversing / random_sorting row orders are on "
-                    "the device yet");
+                    "pi_sign_change walks row ids 0..n-1 (itm-common.hpp:672-674): "
+                    "needs n <= m");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->policy = order;
+    h->use_cycle = order == BXH_ORDER_CYCLE;
+    std::fill(h->ostate.begin(), h->ostate.end(), h->use_cycle ? BXH_ORDER_NONE : order);
+    const size_t B = static_cast<size_t>(h->batch), LC = static_cast<size_t>(h->lcap);
+    HIP_TRY(hipMemset(h->mlist.p, 0, B * LC * sizeof(int2)));
+    std::vector<int> cnt(B, h->n);
+    HIP_TRY(hipMemcpy(h->mcount.p, cnt.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->order_b.p, h->ostate.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    return BXH_OK;
+}
+
+// compute_order::init of the instances `active` selects (all when null)
+int
+bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* remaining)
+{
+    if (!h)
+        return fail(BXH_ERR_INVALID, "null handle");
+    if (order != h->policy)
+        if (int rc = bxh_order_create(h, order))
+            return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    // (the device copy of the per-instance orders is current: it is written
+    // by bxh_order_create and by every sweep)
+    const unsigned char* dev_active = nullptr;
+    if (active) {
+        HIP_TRY(hipStreamSynchronize(h->stream)); // the pinned buffer is reused
+        std::memcpy(h->h_active, active, static_cast<size_t>(h->batch));
+        HIP_TRY(hipMemcpyAsync(h->active.p, h->h_active, static_cast<size_t>(h->batch),
+                               hipMemcpyHostToDevice, h->stream));
+        dev_active = h->active.p;
+    }
     if (h->float_type == BXH_FLOAT)
         hipLaunchKernelGGL((bxh::order_init_kernel<float>),
                            dim3(h->batch),
@@ -1010,7 +1089,9 @@ bxh_order_init(bxh_handle h, int order, int32_t* remaining)
                            h->lds_bytes_init,
                            h->stream,
                            h->dp,
-                           h->ds);
+                           h->ds,
+                           h->order_b.p,
+                           dev_active);
     else
         hipLaunchKernelGGL((bxh::order_init_kernel<double>),
                            dim3(h->batch),
@@ -1018,33 +1099,56 @@ bxh_order_init(bxh_handle h, int order, int32_t* remaining)
                            h->lds_bytes_init,
                            h->stream,
                            h->dp,
-                           h->ds);
+                           h->ds,
+                           h->order_b.p,
+                           dev_active);
     HIP_TRY(hipGetLastError());
     if (remaining) {
         HIP_TRY(hipStreamSynchronize(h->stream));
-        HIP_TRY(hipMemcpy(remaining,
-                          h->vcount.p,
-                          static_cast<size_t>(h->batch) * sizeof(int),
+        HIP_TRY(hipMemcpy(h->h_status, h->status.p,
+                          static_cast<size_t>(h->batch) * sizeof(bxh::DevStatus),
                           hipMemcpyDeviceToHost));
+        for (int b = 0; b != h->batch; ++b)
+            remaining[b] = h->h_status[b].remaining;
     }
     return BXH_OK;
 }
 
+int
+bxh_order_init(bxh_handle h, int order, int32_t* remaining)
+{
+    return bxh_order_init_masked(h, order, nullptr, remaining);
+}
+
+// the list compute_order would walk next: m_order's rows for the
+// infeasibility orders, R otherwise
 int
 bxh_get_violated(bxh_handle h, int inst, int32_t* rows, int32_t* count)
 {
     if (int rc = check_inst(h, inst))
         return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    const int st = h->ostate[static_cast<size_t>(inst)];
+    const bool by_m = st == BXH_ORDER_INFEASIBILITY_DECR || st == BXH_ORDER_INFEASIBILITY_INCR;
     int c = 0;
-    HIP_TRY(hipMemcpy(&c, h->vcount.p + inst, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&c, (by_m ? h->mcount.p : h->vcount.p) + inst, sizeof(int),
+                      hipMemcpyDeviceToHost));
     if (count)
         *count = c;
-    if (rows && c > 0)
-        HIP_TRY(hipMemcpy(rows,
-                          h->vlist.p + static_cast<size_t>(inst) * h->m,
-                          static_cast<size_t>(c) * sizeof(int),
-                          hipMemcpyDeviceToHost));
+    if (rows && c > 0) {
+        if (by_m) {
+            std::vector<int2> tmp(static_cast<size_t>(c));
+            HIP_TRY(hipMemcpy(tmp.data(), h->mlist.p + static_cast<size_t>(inst) * h->lcap,
+                              static_cast<size_t>(c) * sizeof(int2), hipMemcpyDeviceToHost));
+            for (int i = 0; i != c; ++i)
+                rows[i] = tmp[static_cast<size_t>(i)].x;
+        } else {
+            HIP_TRY(hipMemcpy(rows,
+                              h->vlist.p + static_cast<size_t>(inst) * h->lcap,
+                              static_cast<size_t>(c) * sizeof(int),
+                              hipMemcpyDeviceToHost));
+        }
+    }
     return BXH_OK;
 }
 
@@ -1053,10 +1157,9 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
 {
     if (!h || !a || !a->kappa)
         return fail(BXH_ERR_INVALID, "null argument");
-    if (a->order < BXH_ORDER_NONE || a->order > BXH_ORDER_RANDOM_SORTING)
-        return fail(BXH_ERR_UNSUPPORTED,
-                    "only none / reversing / random_sorting row orders are on "
-                    "the device yet");
+    if (a->order != h->policy) // a sweep with another order: a new compute_order
+        if (int rc = bxh_order_create(h, a->order))
+            return rc;
     for (int i = 0; i != h->batch; ++i)
         if (!(a->kappa[i] >= 0.0 && a->kappa[i] < 1.0))
             return fail(BXH_ERR_INVALID, "kappa must be in [0, 1)");
@@ -1079,7 +1182,23 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
     s.theta = a->theta;
     s.obj_amp = a->obj_amp;
     s.is_push = a->is_push;
-    s.order = a->order;
+    // push_and_run of a `cycle` order first moves to the next order
+    // (itm-common.hpp:686-687); every instance keeps its own state
+    bool need_prep = false, need_post = false;
+    for (int b = 0; b != h->batch; ++b) {
+        if (a->active && !a->active[b])
+            continue;
+        int& st = h->ostate[static_cast<size_t>(b)];
+        if (h->use_cycle && a->is_push)
+            st = st + 1 >= BXH_ORDER_CYCLE ? 0 : st + 1;
+        need_prep = need_prep || (st >= BXH_ORDER_INFEASIBILITY_DECR && st <= BXH_ORDER_LAGRANGIAN_INCR);
+        need_post = need_post || st == BXH_ORDER_INFEASIBILITY_DECR || st == BXH_ORDER_INFEASIBILITY_INCR;
+    }
+    std::memcpy(h->h_order, h->ostate.data(), static_cast<size_t>(h->batch) * sizeof(int));
+    HIP_TRY(hipMemcpyAsync(h->order_b.p, h->h_order, static_cast<size_t>(h->batch) * sizeof(int),
+                           hipMemcpyHostToDevice, h->stream));
+    s.order = 0;
+    s.order_b = h->order_b.p;
     s.active = nullptr;
     if (a->active) {
         std::memcpy(h->h_active, a->active, static_cast<size_t>(h->batch));
@@ -1098,8 +1217,28 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
                                    h->stream));
     }
     s.epoch = h->epoch;
-    return h->float_type == BXH_FLOAT ? launch_sweep<float>(h, s)
-                                      : launch_sweep<double>(h, s);
+    if (need_prep) { // the sorts of the infeasibility / lagrangian orders
+        if (h->float_type == BXH_FLOAT)
+            hipLaunchKernelGGL((bxh::order_prep_kernel<float>), dim3(h->batch), dim3(1024), 0,
+                               h->stream, h->dp, h->ds, s);
+        else
+            hipLaunchKernelGGL((bxh::order_prep_kernel<double>), dim3(h->batch), dim3(1024), 0,
+                               h->stream, h->dp, h->ds, s);
+        HIP_TRY(hipGetLastError());
+    }
+    if (int rc = h->float_type == BXH_FLOAT ? launch_sweep<float>(h, s)
+                                             : launch_sweep<double>(h, s))
+        return rc;
+    if (need_post) { // m_order of the new x (itm-common.hpp:893-914)
+        if (h->float_type == BXH_FLOAT)
+            hipLaunchKernelGGL((bxh::order_post_kernel<float>), dim3(h->batch), dim3(h->threads),
+                               h->lds_bytes_init, h->stream, h->dp, h->ds, s);
+        else
+            hipLaunchKernelGGL((bxh::order_post_kernel<double>), dim3(h->batch), dim3(h->threads),
+                               h->lds_bytes_init, h->stream, h->dp, h->ds, s);
+        HIP_TRY(hipGetLastError());
+    }
+    return BXH_OK;
 }
 
 int

@@ -74,15 +74,25 @@ struct DevState
     unsigned* x;         // [batch][2*nwords] u32 halves of the bit_array blocks
     void* rstale;        // [batch][rmax+1] Float: R[].value as the reference's
                          //   persistent R array holds it between rows
-    int* vlist;          // [batch][m] violated rows (compute_order::R)
+    int* vlist;          // [batch][lcap] compute_order::R (the violated rows)
     int* vcount;         // [batch]
     signed char* vflag;  // [batch][m] scratch
     DevStatus* status;   // [batch]
     unsigned long long* prof; // [batch][16] phase ticks (profiling build only)
-    int* vwork;          // [batch][groups][m] private copy of the row list
+    int* vwork;          // [batch][groups][lcap] private copy of the row list
     int* vpart;          // [batch][groups][m] per-owner row activities
     unsigned long long* xbuf; // [batch][2][rmax][2] tagged halves of the row's reduced costs
     unsigned* cnt;       // [batch] row arrivals, [batch] sweep-end arrivals, [1] error
+    // compute_order's second list and scratch (itm-common.hpp:627-915)
+    int lcap;            // capacity of the row lists: max(m, n)
+    int2* mlist;         // [batch][lcap] m_order = {row, infeasibility}
+    int* mcount;         // [batch]
+    int* mrun;           // [batch][lcap] row ids of the sorted m_order / list scratch
+    int2* mtmp;          // [batch][lcap] scratch of the sorts
+    int* slist;          // [batch][lcap] violated rows of the orders that keep R
+    int* vamt;           // [batch][m] infeasibility of every row (0: satisfied)
+    unsigned long long* skey; // [batch][next_pow2(lcap)] sort keys
+    int* sid;            // [batch][next_pow2(lcap)] sort payload
 };
 
 struct Prof
@@ -124,7 +134,8 @@ struct DevSweep
     const double* kappa; // [batch]
     double delta, theta, obj_amp;
     int is_push;
-    int order;
+    int order;                   // row order of every instance ...
+    const int* order_b;          // ... or per instance (compute_order's state), may be null
     const unsigned char* active; // [batch] or null
     unsigned epoch;              // launch number (tags of the row exchange)
 };
@@ -710,9 +721,80 @@ enum
     MS_WAVES = 16  // 64 ints of scratch (also the per-wave partials below)
 };
 
+// Row order of an instance this sweep: 0 none, 1 reversing, 2 random_sorting,
+// 3 / 4 infeasibility decr / incr, 5 / 6 lagrangian decr / incr, 7
+// pi_sign_change (solver_parameters::constraint_order, core:286-296; `cycle`
+// is resolved to one of these by the host, itm-common.hpp:640-658).
+__device__ inline int
+order_of(const DevSweep& a, int inst)
+{
+    return a.order_b ? a.order_b[inst] : a.order;
+}
+
+// infeasibility_local_compute_violated_constraints (itm-common.hpp:893-914):
+// m_order = {k, how far row k is from its bounds} for the violated rows, in
+// increasing k.  Returns their number.
+__device__ inline int
+rebuild_infeasibility(const DevProblem& pb,
+                      const unsigned* x_s,
+                      int* vamt,
+                      int2* mlist,
+                      int* scratch_s /* >= 64 ints */)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    const bool pm1 = pb.kind >= 2;
+
+    for (int k = wave; k < pb.m; k += nwaves) {
+        const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
+        int v = 0;
+        for (int e = rs + lane; e < re; e += 64) {
+            const int j = pb.row_col[e];
+            const int bit = (x_s[j >> 5] >> (j & 31)) & 1u;
+            v += pm1 ? (int)pb.fac_csr[e] * bit : bit;
+        }
+        v = wave_sum(v);
+        if (lane == 0) {
+            int amt = 0;
+            if (pb.bmin[k] > v)
+                amt = pb.bmin[k] - v;
+            else if (pb.bmax[k] < v)
+                amt = v - pb.bmax[k];
+            vamt[k] = amt;
+        }
+    }
+    __syncthreads(); // vamt is only read back by this workgroup (same CU)
+
+    int base = 0;
+    for (int c = 0; c < pb.m; c += T) {
+        const int k = c + tid;
+        const int amt = k < pb.m ? vamt[k] : 0;
+        const bool f = amt != 0;
+        const unsigned long long mask = __ballot(f);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            scratch_s[wave] = __popcll(mask);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w = 0; w < nwaves; ++w) {
+            const int cw = scratch_s[w];
+            if (w < wave)
+                off += cw;
+            tot += cw;
+        }
+        if (f)
+            mlist[base + off + prefix] = make_int2(k, amt);
+        base += tot;
+        __syncthreads();
+    }
+    return base;
+}
+
+// compute_order::init (itm-common.hpp:660-680) of the instances `active`
+// selects (all when null), by each instance's current order.
 template<typename Float>
 __global__ __launch_bounds__(1024) void
-order_init_kernel(DevProblem pb, DevState st)
+order_init_kernel(DevProblem pb, DevState st, const int* order_b, const unsigned char* active)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LdsPlan lp = lds_plan(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float));
@@ -720,21 +802,141 @@ order_init_kernel(DevProblem pb, DevState st)
     int* misc_s = (int*)(smem + lp.off_misc);
     const int inst = blockIdx.x;
     const int tid = threadIdx.x, T = blockDim.x;
+    if (active && !active[inst])
+        return;
+    const int ord = order_b ? order_b[inst] : 0;
 
     const unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
     for (int i = tid; i < 2 * pb.nwords; i += T)
         x_s[i] = xg[i];
     __syncthreads();
 
-    const int cnt = rebuild_violated(pb,
-                                     x_s,
-                                     st.vflag + (size_t)inst * pb.m,
-                                     st.vlist + (size_t)inst * pb.m,
-                                     misc_s + MS_WAVES);
+    int* vlist = st.vlist + (size_t)inst * st.lcap;
+    if (ord == 3 || ord == 4) {
+        const int cnt = rebuild_infeasibility(pb,
+                                              x_s,
+                                              st.vamt + (size_t)inst * pb.m,
+                                              st.mlist + (size_t)inst * st.lcap,
+                                              misc_s + MS_WAVES);
+        if (tid == 0) {
+            st.mcount[inst] = cnt;
+            st.status[inst].remaining = cnt;
+        }
+        return;
+    }
+    if (ord == 7) { // std::iota over `variables` entries (itm-common.hpp:672-674)
+        for (int i = tid; i < pb.n; i += T)
+            vlist[i] = i;
+        // remaining as solver_functor would first see it
+        const int cnt = rebuild_violated(pb,
+                                         x_s,
+                                         st.vflag + (size_t)inst * pb.m,
+                                         st.slist + (size_t)inst * st.lcap,
+                                         misc_s + MS_WAVES);
+        if (tid == 0) {
+            st.vcount[inst] = pb.n;
+            st.status[inst].remaining = cnt;
+        }
+        return;
+    }
+    const int cnt = rebuild_violated(
+      pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES);
     if (tid == 0) {
         st.vcount[inst] = cnt;
         st.status[inst].remaining = cnt;
     }
+}
+
+// The sorts of compute_order::run / push_and_run (itm-common.hpp:690-760,
+// 808-850) ahead of the row loop: m_order by infeasibility (3 / 4), R by pi
+// (5 / 6).  std::sort there is unstable; ties keep their list position here
+// (the canonical tie rule of DESIGN.md, the oracle's SORT_CANONICAL).
+template<typename Float>
+__global__ __launch_bounds__(1024) void
+order_prep_kernel(DevProblem pb, DevState st, DevSweep a)
+{
+    const int inst = blockIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x;
+    if (a.active && !a.active[inst])
+        return;
+    const int ord = order_of(a, inst);
+    if (ord < 3 || ord > 6)
+        return;
+    const bool by_m = ord <= 4;
+    const int n = by_m ? st.mcount[inst] : st.vcount[inst];
+    if (n < 1)
+        return;
+    const int n2 = next_pow2(n < 2 ? 2 : n);
+    const int n2cap = next_pow2(st.lcap < 2 ? 2 : st.lcap);
+    unsigned long long* key = st.skey + (size_t)inst * n2cap;
+    int* id = st.sid + (size_t)inst * n2cap;
+    int2* mlist = st.mlist + (size_t)inst * st.lcap;
+    int2* mtmp = st.mtmp + (size_t)inst * st.lcap;
+    int* mrun = st.mrun + (size_t)inst * st.lcap;
+    int* vlist = st.vlist + (size_t)inst * st.lcap;
+    const Float* pig = (const Float*)st.pi + (size_t)inst * pb.m;
+
+    for (int i = tid; i < n2; i += T) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            if (by_m) {
+                const int2 e = mlist[i];
+                mtmp[i] = e;
+                const unsigned amt = (unsigned)e.y;
+                k = ord == 3 ? (unsigned long long)(0xffffffffu - amt) : (unsigned long long)amt;
+            } else {
+                const int row = vlist[i];
+                mrun[i] = row;
+                // `pi[r] < pi[l]` first (decr) == ascending on the reversed key
+                k = order_key<Float>(pig[row], ord == 5);
+                if (k == ~0ull)
+                    k = ~0ull - 1; // padding stays last
+            }
+        }
+        key[i] = k;
+        id[i] = i;
+    }
+    __syncthreads();
+    bitonic_sort(key, id, n2);
+    for (int i = tid; i < n; i += T) {
+        if (by_m) {
+            const int2 e = mtmp[id[i]];
+            mlist[i] = e;
+            mrun[i] = e.x;
+        } else {
+            vlist[i] = mrun[id[i]];
+        }
+    }
+}
+
+// After a sweep in an infeasibility order: m_order of the new x
+// (itm-common.hpp:720-722, 832-834).
+template<typename Float>
+__global__ __launch_bounds__(1024) void
+order_post_kernel(DevProblem pb, DevState st, DevSweep a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LdsPlan lp = lds_plan(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float));
+    unsigned* x_s = (unsigned*)(smem + lp.off_x);
+    int* misc_s = (int*)(smem + lp.off_misc);
+    const int inst = blockIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x;
+    if (a.active && !a.active[inst])
+        return;
+    const int ord = order_of(a, inst);
+    if (ord != 3 && ord != 4)
+        return;
+    const unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        x_s[i] = xg[i];
+    __syncthreads();
+    const int cnt = rebuild_infeasibility(pb,
+                                          x_s,
+                                          st.vamt + (size_t)inst * pb.m,
+                                          st.mlist + (size_t)inst * st.lcap,
+                                          misc_s + MS_WAVES);
+    if (tid == 0)
+        st.mcount[inst] = cnt;
 }
 
 // One sweep of one instance: compute_order::run / push_and_run
@@ -769,7 +971,12 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
     Float* pig = (Float*)st.pi + (size_t)inst * pb.m;
     unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
     Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
-    int* vlist = st.vlist + (size_t)inst * pb.m;
+    // compute_order::run / push_and_run by this instance's order
+    const int ord = order_of(a, inst);
+    const bool use_m = ord == 3 || ord == 4;          // rows of the sorted m_order
+    const bool keep = use_m || ord == 7;              // R is not recomputed
+    int* vlist = use_m ? st.mrun + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
+    int* out_list = keep ? st.slist + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
     const Float* cost = (const Float*)pb.cost;
 
     const Float kappa = (Float)a.kappa[inst];
@@ -787,20 +994,20 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
 
     MinStd rng;
     rng.s = st.status[inst].rng; // meaningful in thread 0 only
-    const int nrows = st.vcount[inst];
+    const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
     double alg_bytes = 0.0; // thread 0 only
 
     if (tid == 0) {
         misc_s[MS_PICH] = 0;
         // compute_order: random_sorting shuffles the list before the sweep
         // (itm-common.hpp:708-714 / :817-823)
-        if (a.order == 2)
+        if (ord == 2 || ord == 7)
             rng.shuffle(vlist, (unsigned)nrows);
     }
     __syncthreads();
 
     for (int it = 0; it < nrows; ++it) {
-        const int k = (a.order == 1) ? vlist[nrows - 1 - it] : vlist[it];
+        const int k = (ord == 1) ? vlist[nrows - 1 - it] : vlist[it];
         const int rs = pb.row_ptr[k];
         const int r = pb.row_ptr[k + 1] - rs;
 
@@ -952,10 +1159,11 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
         staleg[i] = stale_s[i];
 
     const int cnt = rebuild_violated(
-      pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES);
+      pb, x_s, st.vflag + (size_t)inst * pb.m, out_list, misc_s + MS_WAVES);
 
     if (tid == 0) {
-        st.vcount[inst] = cnt;
+        if (!keep)
+            st.vcount[inst] = cnt;
         DevStatus s = st.status[inst];
         s.remaining = cnt;
         s.pi_changed = misc_s[MS_PICH];
@@ -1211,9 +1419,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     Float* pig = (Float*)st.pi + (size_t)inst * pb.m;
     unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
     Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
-    int* vlist = st.vlist + (size_t)inst * pb.m;
+    // compute_order::run / push_and_run by this instance's order
+    const int ord = order_of(a, inst);
+    const bool use_m = ord == 3 || ord == 4;          // rows of the sorted m_order
+    const bool keep = use_m || ord == 7;              // R is not recomputed
+    int* vlist = use_m ? st.mrun + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
+    int* out_list = keep ? st.slist + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
     // several owners: each works on a private copy of the row list
-    int* vrows = MW ? st.vwork + ((size_t)inst * NG + grp) * pb.m : vlist;
+    int* vrows = MW ? st.vwork + ((size_t)inst * NG + grp) * st.lcap : vlist;
     const Float* cost = (const Float*)pb.cost;
 
     const Float kappa = (Float)a.kappa[inst];
@@ -1236,7 +1449,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 
     MinStd rng;
     rng.s = st.status[inst].rng; // meaningful in thread 0 only
-    const int nrows = st.vcount[inst];
+    const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
     double alg_bytes = 0.0; // thread 0 only
 
     if (MW) {
@@ -1246,11 +1459,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     }
     if (tid == 0) {
         misc_s[MS_PICH] = 0;
-        if (a.order == 2)
+        if (ord == 2 || ord == 7)
             rng.shuffle(vrows, (unsigned)nrows);
         misc_s[MS_RNG] = (int)rng.s;
     }
     __syncthreads();
+    if (MW && ord == 7 && grp == 0) // pi_sign_change keeps the shuffled R
+        for (int i = tid; i < nrows; i += T)
+            vlist[i] = vrows[i];
     rng.s = (unsigned)misc_s[MS_RNG];
 
     const int l8 = tid & 7;
@@ -1266,7 +1482,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     // per-entry descriptor (registers) two and its LDS copy one, so that none
     // of them is waited for at the head of a row.
     auto row_at = [&](int it_) -> int {
-        return (a.order == 1) ? vrows[nrows - 1 - it_] : vrows[it_];
+        return (ord == 1) ? vrows[nrows - 1 - it_] : vrows[it_];
     };
     const int* sub_ptr = MW ? pb.sub_ptr + (size_t)grp * (pb.m + 1) : nullptr;
     struct RowX
@@ -2075,13 +2291,13 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                                       cnt_end,
                                       err_word,
                                       st.vflag + ((size_t)inst * NG + grp) * pb.m,
-                                      grp == 0 ? vlist : vrows,
+                                      grp == 0 ? out_list : vrows,
                                       misc_s + MS_WAVES);
     } else {
         for (int i = tid; i < 2 * pb.nwords; i += T)
             xg[i] = x_s[i];
         cnt = rebuild_violated(
-          pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES);
+          pb, x_s, st.vflag + (size_t)inst * pb.m, out_list, misc_s + MS_WAVES);
     }
     BXH_STAMP(7);
 #ifdef BXH_PROFILE
@@ -2091,7 +2307,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 #endif
 
     if (tid == 0 && grp == 0) {
-        st.vcount[inst] = cnt;
+        if (!keep)
+            st.vcount[inst] = cnt;
         DevStatus s = st.status[inst];
         s.remaining = cnt;
         s.pi_changed = misc_s[MS_PICH];

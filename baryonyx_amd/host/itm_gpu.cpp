@@ -369,7 +369,13 @@ struct device_batch
     void set_x(int i, const bit_array& x) { check(bxh_set_x(h, i, x.w.data())); }
     void get_x(int i, bit_array& x) { check(bxh_get_x(h, i, x.w.data())); }
     void set_rng(int i, const random_engine& e) { check(bxh_set_rng(h, i, engine_state(e))); }
-    void order_init(int order) { check(bxh_order_init(h, order, nullptr)); }
+    // compute_order's constructor, once per solve / optimize run
+    void order_create(int order) { check(bxh_order_create(h, order)); }
+    // compute_order::init of every instance, or of those `mask` selects
+    void order_init(int order, const std::vector<std::uint8_t>* mask = nullptr)
+    {
+        check(bxh_order_init_masked(h, order, mask ? mask->data() : nullptr, nullptr));
+    }
     // one compute_order::run / push_and_run of the active instances
     void sweep(double delta, double theta, bool push, double obj_amp, int order)
     {
@@ -520,6 +526,7 @@ solve_problem(const context& ctx, const problem& pb)
 
         slv.set_x(0, x);
         slv.set_rng(0, rng);
+        slv.order_create(order);
         slv.order_init(order);
 
         for (long i = 0; i != p.limit; ++i) {
@@ -951,6 +958,10 @@ optimize_problem(const context& ctx, const problem& pb)
         w.phase = w.push < p.pushes_limit ? PH_PUSH : PH_REINIT;
     };
 
+    // one compute_order per worker, constructed once (itm-optimizer-common.hpp:655)
+    slv.order_create(order);
+    std::vector<std::uint8_t> init_mask(static_cast<size_t>(workers), 0);
+
     long sweeps = 0;
     for (;;) {
         if (time_limit > 0 && elapsed() > time_limit)
@@ -960,10 +971,12 @@ optimize_problem(const context& ctx, const problem& pb)
 
         // -- restarts (reinit + compute.init), per worker in id order --------
         bool any_init = false;
+        std::fill(init_mask.begin(), init_mask.end(), std::uint8_t{ 0 });
         for (int b = 0; b != workers; ++b) {
             worker& w = wk[b];
             if (w.phase != PH_REINIT)
                 continue;
+            init_mask[static_cast<size_t>(b)] = 1;
             ++w.calls;
             w.kappa_start = static_cast<Float>(best_recorder.reinit(lctx[b], b, p, w.x));
             w.kappa = w.kappa_start;
@@ -976,7 +989,7 @@ optimize_problem(const context& ctx, const problem& pb)
             any_init = true;
         }
         if (any_init)
-            slv.order_init(order); // violated rows of unchanged x are unchanged
+            slv.order_init(order, &init_mask); // compute.init of the restarted workers only
 
         // -- one sweep of everybody: run() for MAIN / PUSH_ITER, push_and_run
         //    for PUSH (two launches when both kinds are present) -------------

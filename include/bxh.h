@@ -157,12 +157,27 @@ int bxh_get_rng(bxh_handle h, int inst, uint32_t* state);
 /* Solver::reset() (e.g. itm-solver-inequalities-01.cpp:109-113) */
 int bxh_reset(bxh_handle h, int inst);
 
+/* compute_order's constructor (itm-common.hpp:640-658) for every instance:
+ * `order` is a bxh_order (solver_parameters::constraint_order, core:286-296);
+ * BXH_ORDER_CYCLE starts as `none` and every instance steps to the next order
+ * at each of its push sweeps (itm-common.hpp:686-687).  R and m_order start
+ * as the reference's value-initialised lists of `n` entries.  pi_sign_change
+ * (and cycle) walk row ids 0..n-1 (itm-common.hpp:672-674): BXH_ERR_UNSUPPORTED
+ * when n > m, where the reference reads past its arrays. */
+int bxh_order_create(bxh_handle h, int order);
 /* compute_order::init (itm-common.hpp:660-680): rebuild every instance's
- * violated-row list from its current x; remaining[] may be NULL, in which
- * case the call only enqueues the kernel on the stream. */
+ * list (R, or m_order for the infeasibility orders, or iota for
+ * pi_sign_change) from its current x; remaining[] may be NULL, in which
+ * case the call only enqueues the kernel on the stream.  An `order` other than
+ * the one last given to bxh_order_create first re-creates the object. */
 int bxh_order_init(bxh_handle h, int order, int32_t* remaining_batch);
-/* the current list (compute_order::R) of one instance */
-int bxh_get_violated(bxh_handle h, int inst, int32_t* rows_m, int32_t* count);
+/* the same for the instances with active[i] != 0 only (a restart of some
+ * workers, itm-optimizer-common.hpp:663-666); active may be NULL = all */
+int bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active_batch,
+                          int32_t* remaining_batch);
+/* the list one instance walks next (R, or the rows of m_order); rows needs
+ * room for max(m, n) entries */
+int bxh_get_violated(bxh_handle h, int inst, int32_t* rows, int32_t* count);
 
 /* One sweep of all active instances; blocks until the status is on the host. */
 int bxh_sweep(bxh_handle h, const bxh_sweep_args* args, bxh_status* status_batch);

@@ -26,10 +26,17 @@ CASES = [
     ("flat30-7.lp", dict(limit=CAP, delta=0.001, kappa_min=0.3, kappa_step=1e-10, kappa_max=1.0,
                          order=1, w=0.0)),
     ("aim-50-1_6-yes1-2.lp", dict(limit=CAP, theta=0.6, delta=0.01, alpha=1.0, w=20.0)),
+    # the other constraint orders through the whole solve() loop
+    ("assignment_problem_1.lp", dict(order=3)),
+    ("assignment_problem_2.lp", dict(order=4)),
+    ("negative-coeff4.lp", dict(limit=50, w=0.05, order=5)),
+    ("negative-coeff.lp", dict(limit=50, w=0.05, order=6)),
+    ("aim-50-1_6-yes1-2.lp", dict(limit=CAP, theta=0.6, delta=0.01, alpha=1.0, w=20.0, order=5)),
 ]
 
 
-@pytest.mark.parametrize("name,params", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("name,params", CASES,
+                         ids=[c[0] + ("-order%d" % c[1]["order"] if "order" in c[1] else "") for c in CASES])
 def test_solve_fixture_matches_oracle(oracle, name, params):
     path = os.path.join(LP, name)
     kw = dict(seed=123456789)

@@ -50,7 +50,8 @@ def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweep
     rem = dev.order_init(order)
     for b, s in enumerate(orcs):
         assert np.array_equal(dev.violated(b), s.violated()), f"initial violated list, inst {b}"
-        assert rem[b] == len(s.violated())
+        if order != 7:  # pi_sign_change walks iota(n); remaining counts the violated rows
+            assert rem[b] == len(s.violated())
 
     kappa = np.array([0.0 + 0.01 * b for b in range(batch)])
     for it in range(sweeps):
@@ -102,3 +103,45 @@ def test_scpnrh_shaped_rows(oracle, bxh, groups, monkeypatch):
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=4, push_at=(2,))
     inst = synth.make_scp(100, 6000, 0.08, "real", 32)
     run_case(oracle, bxh, inst, 0, False, 0, 0.0, batch=2, sweeps=4, push_at=(3,))
+
+
+ORDER_CASES = [
+    # (name, maker, float_type, maximize, order, x0_density, push_at)
+    ("infeas-decr-pm1", lambda: synth.make_pm1(50, 250, 0.06, "int", 41), 1, False, 3, 0.3, (5, 9)),
+    ("infeas-incr-pm1-eq", lambda: synth.make_pm1(40, 250, 0.06, "real", 42, equalities=True), 1, False, 4, 0.3, (5, 9)),
+    ("infeas-decr-scp-f32", lambda: synth.make_scp(60, 400, 0.06, "int", 43), 0, False, 3, 0.0, (4,)),
+    ("lagrangian-decr-scp", lambda: synth.make_scp(60, 400, 0.06, "real", 44), 1, False, 5, 0.0, (5, 9)),
+    ("lagrangian-incr-spp-max", lambda: synth.make_spp(40, 300, 0.06, "int", 45), 1, True, 6, 0.2, (5, 9)),
+    ("pi-sign-change", lambda: synth.make_scp(80, 60, 0.15, "real", 46), 1, False, 7, 0.1, (5, 9)),
+    ("pi-sign-change-pm1", lambda: synth.make_pm1(90, 70, 0.12, "int", 47), 1, False, 7, 0.2, (3, 4)),
+    ("cycle", lambda: synth.make_scp(80, 60, 0.15, "int", 48), 1, False, 8, 0.1, tuple(range(1, 20))),
+    ("cycle-pm1-f32", lambda: synth.make_pm1(90, 70, 0.12, "real", 49), 0, False, 8, 0.2,
+     tuple(range(0, 20, 2))),
+]
+
+
+@pytest.mark.parametrize("groups", ["1", "4"])
+@pytest.mark.parametrize("case", ORDER_CASES, ids=[c[0] for c in ORDER_CASES])
+def test_row_orders_match_oracle(oracle, bxh, case, groups, monkeypatch):
+    """The sorting orders of compute_order (infeasibility, lagrangian),
+    pi_sign_change and cycle (itm-common.hpp:682-880), including the
+    value-initialised m_order a cycle run meets first."""
+    monkeypatch.delenv("BXH_FORCE_V1", raising=False)
+    monkeypatch.setenv("BXH_GROUPS", groups)
+    _, maker, float_type, maximize, order, x0p, push_at = case
+    run_case(oracle, bxh, maker(), float_type, maximize, order, x0p, sweeps=20, push_at=push_at)
+
+
+def test_row_orders_lane_per_column_kernel(oracle, bxh, monkeypatch):
+    monkeypatch.setenv("BXH_FORCE_V1", "1")
+    for case in (ORDER_CASES[0], ORDER_CASES[3], ORDER_CASES[7]):
+        _, maker, float_type, maximize, order, x0p, push_at = case
+        run_case(oracle, bxh, maker(), float_type, maximize, order, x0p, sweeps=20, push_at=push_at)
+
+
+def test_pi_sign_change_needs_n_le_m(bxh):
+    inst = synth.make_scp(20, 50, 0.2, "int", 50)
+    dev = bxh.DeviceBatch(inst, inst.dense_costs(), 1)
+    with pytest.raises(RuntimeError):
+        dev.order_create(7)
+    dev.close()
