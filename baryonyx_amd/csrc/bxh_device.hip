@@ -115,6 +115,10 @@ struct bxh_handle_s
     DevBuf<int> order_b;       // the same, on the device
     int* h_order = nullptr;    // pinned staging
     DevBuf<int2> mlist, mtmp;
+    // inequalities-Z
+    DevBuf<int> fac32, col_fac, ex_start, ex_count, ex_flat;
+    DevBuf<signed char> zkind;
+    DevBuf<unsigned char> zscratch;
     DevBuf<int> mcount, mrun, slist, vamt, sid;
     DevBuf<unsigned long long> skey;
     DevBuf<signed char> vflag;
@@ -273,6 +277,8 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
                 BXH_V2(false, 8);
         }
 #undef BXH_V2
+    } else if (h->version == 3) {
+        BXH_LAUNCH((bxh::sweep_kernel_z<Float>));
     } else {
         if (pm1)
             BXH_LAUNCH((bxh::sweep_kernel<Float, true>));
@@ -314,10 +320,6 @@ bxh_create(const bxh_problem* pb,
         return fail(BXH_ERR_INVALID, "null problem array");
     if (kind < BXH_EQ_01 || kind > BXH_INEQ_Z)
         return fail(BXH_ERR_INVALID, "unknown solver kind");
-    if (kind == BXH_INEQ_Z)
-        return fail(BXH_ERR_UNSUPPORTED,
-                    "inequalities-Z (general integer coefficients) is not on "
-                    "the device yet");
     if (float_type != BXH_FLOAT && float_type != BXH_DOUBLE)
         return fail(BXH_ERR_UNSUPPORTED,
                     "only float and double exist on the device (long double "
@@ -368,7 +370,7 @@ bxh_create(const bxh_problem* pb,
         if (pb->col[e] < 0 || pb->col[e] >= n)
             return fail(BXH_ERR_INVALID, "column index out of range");
         const int f = pb->factor ? pb->factor[e] : 1;
-        if (pm1 ? (f != 1 && f != -1) : (f != 1))
+        if (kind == BXH_INEQ_Z ? f == 0 : (pm1 ? (f != 1 && f != -1) : (f != 1)))
             return fail(BXH_ERR_INVALID,
                         "coefficient not allowed by this solver kind");
         ++col_ptr[pb->col[e] + 1];
@@ -385,7 +387,8 @@ bxh_create(const bxh_problem* pb,
     // then how many workgroups (column owners) cooperate on one instance: all
     // of them must be resident together, one per CU ----------------------
     const char* force_v1 = std::getenv("BXH_FORCE_V1");
-    const bool v2_ok = cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
+    const bool zsolver = kind == BXH_INEQ_Z;
+    const bool v2_ok = !zsolver && cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
     int groups = 1;
     if (v2_ok) {
         int cus = 256;
@@ -460,6 +463,7 @@ bxh_create(const bxh_problem* pb,
     h->nnzp = nnzp; // stride of one owner's slice
     std::vector<int> col_row(static_cast<size_t>(nnzp) * groups, m), row_pos(static_cast<size_t>(nnz));
     std::vector<signed char> fac_csr(pm1 ? nnz : 0);
+    std::vector<int> fac32(zsolver ? nnz : 0), col_fac(zsolver ? static_cast<size_t>(nnzp) : 0, 0);
     {
         std::vector<int> fill(col_start);
         for (int k = 0; k != m; ++k)
@@ -473,6 +477,11 @@ bxh_create(const bxh_problem* pb,
                     fac_csr[e] = static_cast<signed char>(pb->factor[e]);
                     if (pb->factor[e] < 0)
                         col_row[at] |= 0x40000000;
+                }
+                if (zsolver) {
+                    const int f = pb->factor ? pb->factor[e] : 1;
+                    fac32[e] = f;
+                    col_fac[at] = f < 0 ? -f : f;
                 }
             }
     }
@@ -545,7 +554,7 @@ bxh_create(const bxh_problem* pb,
             bmin[k] = bmax[k] = cmin;
             bneg[k] = lower;
             break;
-        default: // itm-solver-inequalities-101.cpp:99-129
+        case BXH_INEQ_101: // itm-solver-inequalities-101.cpp:99-129
             if (cmin == cmax) {
                 bmin[k] = cmin;
                 bmax[k] = cmax;
@@ -555,6 +564,24 @@ bxh_create(const bxh_problem* pb,
             }
             bneg[k] = lower;
             break;
+        default: { // itm-solver-inequalities-Z.cpp:125-187 (bounds)
+            int lower_sum = 0, upper_sum = 0;
+            for (int e = rs; e != re; ++e) {
+                const int f = pb->factor ? pb->factor[e] : 1;
+                if (f > 0)
+                    upper_sum += f;
+                else
+                    lower_sum += f;
+            }
+            if (cmin == cmax) {
+                bmin[k] = cmin;
+                bmax[k] = cmax;
+            } else {
+                bmin[k] = std::max(lower_sum, cmin);
+                bmax[k] = std::min(upper_sum, cmax);
+            }
+            break;
+        }
         }
         if (bmin[k] > bmax[k])
             return fail(BXH_ERR_INVALID, "constraint with min > max");
@@ -606,6 +633,83 @@ bxh_create(const bxh_problem* pb,
     h->version = 1;
     h->lds_bytes = static_cast<size_t>(lp.total);
     h->threads = std::min(1024, std::max(64, bxh::next_pow2(rmax)));
+    // ---- inequalities-Z: sub-solver of every row (inequalities-Z.cpp:125-187)
+    //      and the feasible patterns of the exhaustive rows
+    //      (exhaustive-solver.hpp:111-167) --------------------------------------
+    std::vector<signed char> zkind;
+    std::vector<int> ex_start, ex_count, ex_flat;
+    if (zsolver) {
+        zkind.assign(static_cast<size_t>(m), 4);
+        ex_start.assign(static_cast<size_t>(m), 0);
+        ex_count.assign(static_cast<size_t>(m), 0);
+        for (int k = 0; k != m; ++k) {
+            const int rs = pb->row_ptr[k], len = pb->row_ptr[k + 1] - rs;
+            int lower = 0, upper = 0;
+            int z = 4; // linear
+            for (int e = rs; e != rs + len; ++e) {
+                const int f = fac32[e];
+                if (f > 0)
+                    upper += f;
+                else
+                    lower += f;
+                if (f < -1 || f > 1)
+                    z = 0; // branch and bound
+            }
+            if (z == 0 && len < 10) // maximum_factor_exhaustive_solver, :39
+                z = 1;
+            if (pb->cmin[k] != pb->cmax[k] && (lower >= pb->cmin[k] || upper <= pb->cmax[k])) {
+                if (z == 0)
+                    z = 2; // unconstrained branch and bound
+                else if (z == 1)
+                    z = 3; // unconstrained exhaustive
+            }
+            zkind[k] = static_cast<signed char>(z);
+            if (z == 1 || z == 3) {
+                // The reference walks a binary counter whose least significant
+                // digit is the LAST element, starting at 0..01, and also
+                // evaluates the states in the middle of every carry (so some
+                // patterns appear more than once); that order decides ties.
+                ex_start[k] = static_cast<int>(ex_flat.size());
+                int nb = 0;
+                std::vector<signed char> digit(static_cast<size_t>(len), 0);
+                digit.back() = 1;
+                auto visit = [&]() {
+                    int sum = 0;
+                    for (int jx = 0; jx != len; ++jx)
+                        if (digit[jx])
+                            sum += fac32[rs + jx];
+                    if (bmin[k] <= sum && sum <= bmax[k]) {
+                        ++nb;
+                        for (int jx = 0; jx != len; ++jx)
+                            ex_flat.push_back(digit[jx] ? fac32[rs + jx] : 0);
+                    }
+                };
+                bool done = false;
+                while (!done) {
+                    int pos = len - 1;
+                    for (;;) {
+                        visit();
+                        if (++digit[pos] <= 1)
+                            break;
+                        digit[pos] = 0;
+                        if (pos == 0) {
+                            done = true;
+                            break;
+                        }
+                        --pos;
+                    }
+                }
+                if (nb <= 0)
+                    return fail(BXH_ERR_INVALID, "a constraint has no feasible assignment");
+                ex_count[k] = nb;
+            }
+        }
+        const int zl = bxh::lds_bytes_z(m, h->nwords, rmax, static_cast<int>(h->fsize));
+        if (zl > lds_limit)
+            return fail(BXH_ERR_UNSUPPORTED, "instance does not fit the Z kernel's LDS plan");
+        h->version = 3;
+        h->lds_bytes = static_cast<size_t>(zl);
+    }
     if (v2_ok) {
         const int np = cmax <= 64 ? 4 : (cmax <= 80 ? 5 : (cmax <= 96 ? 6 : 8));
         // 16 staging slots per wave; as many waves (up to 8) as LDS allows
@@ -657,6 +761,16 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->bmax.upload(bmax));
     HIP_TRY(h->bneg.upload(bneg));
     HIP_TRY(h->fac_csr.upload(fac_csr));
+    if (zsolver) {
+        if (ex_flat.empty())
+            ex_flat.push_back(0);
+        HIP_TRY(h->fac32.upload(fac32));
+        HIP_TRY(h->col_fac.upload(col_fac));
+        HIP_TRY(h->zkind.upload(zkind));
+        HIP_TRY(h->ex_start.upload(ex_start));
+        HIP_TRY(h->ex_count.upload(ex_count));
+        HIP_TRY(h->ex_flat.upload(ex_flat));
+    }
     HIP_TRY(h->sub_ptr.upload(sub_ptr));
     HIP_TRY(h->sub_e.upload(sub_e));
     {
@@ -713,6 +827,9 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->rstale.alloc(B * (rmax + 1) * h->fsize));
     HIP_TRY(h->x.alloc(B * 2 * h->nwords));
     HIP_TRY(h->vlist.alloc(B * LC));
+    const size_t zbytes = zsolver ? ((bxh::zscratch_size(rmax, static_cast<int>(h->fsize)) + 255) & ~size_t{ 255 }) : 0;
+    if (zsolver)
+        HIP_TRY(h->zscratch.alloc(B * zbytes));
     {
         const size_t n2cap = static_cast<size_t>(bxh::next_pow2(static_cast<int>(std::max<size_t>(LC, 2))));
         HIP_TRY(h->mlist.alloc(B * LC));
@@ -776,6 +893,10 @@ bxh_create(const bxh_problem* pb,
             BXH_SET_LDS((bxh::sweep_kernel<float, true>));
             BXH_SET_LDS((bxh::sweep_kernel<double, false>));
             BXH_SET_LDS((bxh::sweep_kernel<double, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_z<float>));
+            BXH_SET_LDS((bxh::sweep_kernel_z<double>));
+            BXH_SET_LDS((bxh::order_post_kernel<float>));
+            BXH_SET_LDS((bxh::order_post_kernel<double>));
             BXH_SET_LDS((bxh::order_init_kernel<float>));
             BXH_SET_LDS((bxh::order_init_kernel<double>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, false>));
@@ -840,6 +961,12 @@ bxh_create(const bxh_problem* pb,
     dp.col_row = h->col_row.p;
     dp.col_row16 = h->col_row16.p;
     dp.fac_csr = h->fac_csr.p;
+    dp.fac32 = h->fac32.p;
+    dp.col_fac = h->col_fac.p;
+    dp.zkind = h->zkind.p;
+    dp.ex_start = h->ex_start.p;
+    dp.ex_count = h->ex_count.p;
+    dp.ex_flat = h->ex_flat.p;
     dp.bmin = h->bmin.p;
     dp.bmax = h->bmax.p;
     dp.bneg = h->bneg.p;
@@ -866,6 +993,8 @@ bxh_create(const bxh_problem* pb,
     ds.vamt = h->vamt.p;
     ds.skey = h->skey.p;
     ds.sid = h->sid.p;
+    ds.zscratch = h->zscratch.p;
+    ds.zscratch_bytes = zbytes;
     ds.vpart = h->vpart.p;
     ds.xbuf = h->xbuf.p;
     ds.cnt = h->cnt.p;
@@ -1255,9 +1384,13 @@ bxh_status_sync(bxh_handle h, bxh_status* out)
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rc = drain_events(h))
         return rc;
-    if (h->groups > 1) {
+    if (h->groups > 1 || h->version == 3) {
         unsigned err = 0;
         HIP_TRY(hipMemcpy(&err, h->cnt.p + 2 * h->batch, sizeof err, hipMemcpyDeviceToHost));
+        if (err == 2u)
+            return fail(BXH_ERR_DEVICE,
+                        "the branch-and-bound search of a constraint exceeded its "
+                        "node budget (branch-and-bound-solver.hpp has none)");
         if (err)
             return fail(BXH_ERR_DEVICE,
                         "a workgroup timed out waiting for its partners (the "
@@ -1330,6 +1463,8 @@ bxh_row_bytes(bxh_handle h, double* bytes_m)
             b += static_cast<double>(h->h_col_ptr[j + 1] - h->h_col_ptr[j]) * (4.0 + 2.0 * F);
         }
         const double r = static_cast<double>(re - rs);
+        if (h->kind == BXH_INEQ_Z) // the repair pass walks every column again; 4 B per coefficient
+            b = 2.0 * b + 4.0 * r;
         b += r * (4.0 + 5.0 * F) + 2.0 * F + static_cast<double>((re - rs + 7) / 8) * 2.0;
         bytes_m[k] = b;
     }

@@ -50,6 +50,13 @@ struct DevProblem
     const void* desc_cost;     // [nnz] Float: cost of the descriptor's column
     const unsigned* ownmask;   // [groups][2*nwords] x bits of each owner
     const signed char* fac_csr; // [nnz]  coefficient of CSR element (101 kinds)
+    // inequalities-Z (general integer coefficients)
+    const int* fac32;          // [nnz]   coefficient of CSR element
+    const int* col_fac;        // [nnzp]  |coefficient| of CSC slot q (0 in padding)
+    const signed char* zkind;  // [m]     sub-solver of row k (ZKind)
+    const int* ex_start;       // [m]     first pattern of row k in ex_flat (exhaustive rows)
+    const int* ex_count;       // [m]     number of patterns
+    const int* ex_flat;        //         patterns: factor or 0 per element, row after row
     const int* bmin;           // [m] clamped as the Solver constructor does
     const int* bmax;           // [m]
     const int* bneg;           // [m] negative_factor (== c_size of the row)
@@ -93,6 +100,8 @@ struct DevState
     int* vamt;           // [batch][m] infeasibility of every row (0: satisfied)
     unsigned long long* skey; // [batch][next_pow2(lcap)] sort keys
     int* sid;            // [batch][next_pow2(lcap)] sort payload
+    unsigned char* zscratch; // [batch][zscratch_bytes] node stack of the B&B rows
+    size_t zscratch_bytes;
 };
 
 struct Prof
@@ -622,7 +631,7 @@ rebuild_violated(const DevProblem& pb,
 {
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
-    const bool pm1 = pb.kind >= 2;
+    const bool pm1 = pb.kind == 2 || pb.kind == 3;
 
     for (int k = wave; k < pb.m; k += nwaves) {
         const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
@@ -630,7 +639,7 @@ rebuild_violated(const DevProblem& pb,
         for (int e = rs + lane; e < re; e += 64) {
             const int j = pb.row_col[e];
             const int bit = (x_s[j >> 5] >> (j & 31)) & 1u;
-            v += pm1 ? (int)pb.fac_csr[e] * bit : bit;
+            v += pb.kind == 4 ? pb.fac32[e] * bit : (pm1 ? (int)pb.fac_csr[e] * bit : bit);
         }
         v = wave_sum(v);
         if (lane == 0)
@@ -743,7 +752,7 @@ rebuild_infeasibility(const DevProblem& pb,
 {
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
-    const bool pm1 = pb.kind >= 2;
+    const bool pm1 = pb.kind == 2 || pb.kind == 3;
 
     for (int k = wave; k < pb.m; k += nwaves) {
         const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
@@ -751,7 +760,7 @@ rebuild_infeasibility(const DevProblem& pb,
         for (int e = rs + lane; e < re; e += 64) {
             const int j = pb.row_col[e];
             const int bit = (x_s[j >> 5] >> (j & 31)) & 1u;
-            v += pm1 ? (int)pb.fac_csr[e] * bit : bit;
+            v += pb.kind == 4 ? pb.fac32[e] * bit : (pm1 ? (int)pb.fac_csr[e] * bit : bit);
         }
         v = wave_sum(v);
         if (lane == 0) {
@@ -1279,6 +1288,495 @@ rebuild_violated_owners(const DevProblem& pb,
         __syncthreads();
     }
     return base;
+}
+
+// ---------------------------------------------------------------------------
+// inequalities-Z: general integer coefficients (itm-solver-inequalities-Z.cpp).
+enum ZKind : int // :73-80
+{
+    Z_BB = 0,
+    Z_EXHAUSTIVE = 1,
+    Z_UNCONSTRAINED_BB = 2,
+    Z_UNCONSTRAINED_EXHAUSTIVE = 3,
+    Z_LINEAR = 4
+};
+
+// LDS of the Z kernel: the plan of the lane-per-column kernel, then the
+// factor of every R position and a 0/1 result per position.
+__host__ __device__ inline int
+lds_bytes_z(int m, int nwords, int rmax, int fsize)
+{
+    const LdsPlan lp = lds_plan(m, nwords, rmax, fsize);
+    return lp.total + 2 * (((rmax + 1) * 4 + 15) & ~15);
+}
+
+// Node stack of branch_and_bound_solver (branch-and-bound-solver.hpp:195-536)
+// in global memory: per node a 0/1 vector (bit set), the sums and the level.
+__host__ __device__ inline size_t
+zscratch_size(int rmax, int fsize)
+{
+    const size_t words = static_cast<size_t>((rmax + 31) / 32);
+    const size_t depth = static_cast<size_t>(rmax) + 2;
+    // vars[depth][words] + solution[words] + sumr[depth] + sumf[depth] + level[depth]
+    return (depth + 1) * words * 4 + depth * (static_cast<size_t>(fsize) + 8) + 64;
+}
+
+// One thread: the depth-first search of branch_and_bound_solver::solve
+// (:450-533) over the items in R order.  The reference first sorts the items
+// with item::operator< (:212-220) -- R was just sorted by calculator_sort, on
+// which that (stable) sort is the identity -- and afterwards by (result,
+// value): a stable partition here.  Writes the 0/1 result of every position to
+// res[]; returns false when the node budget is exhausted.
+template<typename Float>
+__device__ inline bool
+bb_search(const Float* val_s,
+          const int* id_s,
+          const int* fz_s,
+          int n,
+          int b_min,
+          int b_max,
+          bool maximize,
+          unsigned char* scratch,
+          int* res)
+{
+    const int W = (n + 31) / 32;
+    const int depth = n + 2;
+    unsigned* vars = reinterpret_cast<unsigned*>(scratch);          // [depth][W]
+    unsigned* sol = vars + (size_t)depth * W;                       // [W]
+    Float* sumr = reinterpret_cast<Float*>(
+      scratch + ((((size_t)depth + 1) * W * 4 + 15) & ~(size_t)15)); // [depth]
+    int* sumf = reinterpret_cast<int*>(sumr + depth);               // [depth]
+    int* level = sumf + depth;                                      // [depth]
+
+    for (int i = 0; i < n; ++i) // negative coefficients: complemented variable
+        if (fz_s[i] < 0) {
+            b_min += -fz_s[i];
+            b_max += -fz_s[i];
+        }
+    auto r_of = [&](int i) -> Float { return val_s[id_s[i]]; };
+    auto f_of = [&](int i) -> int { return fz_s[i] < 0 ? -fz_s[i] : fz_s[i]; };
+
+    const Float inf = __builtin_huge_val();
+    Float lower_bound = maximize ? -inf : inf;
+    auto is_best = [&](Float z) -> bool { return maximize ? z > lower_bound : z < lower_bound; };
+    for (int w = 0; w < W; ++w)
+        sol[w] = 0u;
+    int top = -1;
+    auto copy_sol = [&](int node) {
+        for (int w = 0; w < W; ++w)
+            sol[w] = vars[(size_t)node * W + w];
+    };
+    auto push0 = [&]() {
+        ++top;
+        for (int w = 0; w < W; ++w)
+            vars[(size_t)top * W + w] = 0u;
+        sumr[top] = 0;
+        sumf[top] = 0;
+        level[top] = 0;
+    };
+    auto push1 = [&]() {
+        ++top;
+        for (int w = 0; w < W; ++w)
+            vars[(size_t)top * W + w] = 0u;
+        vars[(size_t)top * W] = 1u;
+        sumr[top] = r_of(0);
+        sumf[top] = f_of(0);
+        level[top] = 0;
+    };
+    const bool equality = b_max == b_min;
+    if (equality) { // solve_equality, :386-409
+        push0();
+        if (sumf[top] == b_min) {
+            copy_sol(top);
+            top = -1; // returns at once
+        } else {
+            push1();
+            if (sumf[top] == b_min) {
+                copy_sol(top);
+                --top;
+            }
+        }
+    } else { // solve_inequality, :411-440
+        push0();
+        if (b_min <= sumf[top] && sumf[top] <= b_max)
+            copy_sol(top);
+        else if (sumf[top] > b_max)
+            --top;
+        push1();
+        if (b_min <= sumf[top] && sumf[top] <= b_max)
+            copy_sol(top);
+        else if (sumf[top] > b_max)
+            --top;
+    }
+    long budget = 50000000L; // every wave must reach the end of the kernel
+    while (top >= 0) { // make_next_*_node, :307-384
+        if (--budget < 0)
+            return false;
+        const int lv = level[top] + 1;
+        if (lv >= n) {
+            --top;
+            continue;
+        }
+        level[top] = lv;
+        const int child = top + 1;
+        for (int w = 0; w < W; ++w)
+            vars[(size_t)child * W + w] = vars[(size_t)top * W + w];
+        vars[(size_t)child * W + (lv >> 5)] |= 1u << (lv & 31);
+        sumr[child] = sumr[top] + r_of(lv);
+        sumf[child] = sumf[top] + f_of(lv);
+        level[child] = lv;
+        top = child;
+        if (equality) {
+            if (sumf[top] == b_min) {
+                if (is_best(sumr[top])) {
+                    copy_sol(top);
+                    lower_bound = sumr[top];
+                }
+                --top;
+            }
+        } else {
+            if (b_min <= sumf[top] && sumf[top] <= b_max) {
+                if (is_best(sumr[top])) {
+                    copy_sol(top);
+                    lower_bound = sumr[top];
+                }
+            } else if (sumf[top] > b_max) {
+                --top;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const int bit = (sol[i >> 5] >> (i & 31)) & 1u;
+        res[i] = fz_s[i] > 0 ? bit : 1 - bit;
+    }
+    return true;
+}
+
+// One sweep of one instance of the Z solver: compute_order::run /
+// push_and_run around compute_update_row / push_and_compute_update_row of
+// itm-solver-inequalities-Z.cpp:441-564 (one workgroup per instance).
+template<typename Float>
+__global__ __launch_bounds__(1024) void
+sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int inst = blockIdx.x;
+    if (a.active && !a.active[inst])
+        return;
+
+    const LdsPlan lp = lds_plan(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float));
+    Float* pi_s = (Float*)(smem + lp.off_pi);
+    unsigned* x_s = (unsigned*)(smem + lp.off_x);
+    Float* val_s = (Float*)(smem + lp.off_val);
+    unsigned long long* key_s = (unsigned long long*)(smem + lp.off_key);
+    int* id_s = (int*)(smem + lp.off_id);
+    Float* stale_s = (Float*)(smem + lp.off_stale);
+    int* misc_s = (int*)(smem + lp.off_misc);
+    Float* d_s = (Float*)(misc_s + MS_D);
+    int* fz_s = (int*)(smem + lp.total);                                   // R[i].f
+    int* res_s = (int*)(smem + lp.total + (((pb.rmax + 1) * 4 + 15) & ~15)); // 0/1 per position
+
+    const int tid = threadIdx.x, T = blockDim.x;
+    const bool maximize = pb.maximize != 0;
+
+    Float* P = (Float*)st.P + (size_t)inst * pb.nnzp;
+    Float* pig = (Float*)st.pi + (size_t)inst * pb.m;
+    unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
+    Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
+    const int ord = order_of(a, inst);
+    const bool use_m = ord == 3 || ord == 4;
+    const bool keep = use_m || ord == 7;
+    int* vlist = use_m ? st.mrun + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
+    int* out_list = keep ? st.slist + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
+    const Float* cost = (const Float*)pb.cost;
+    unsigned char* scratch = st.zscratch + (size_t)inst * st.zscratch_bytes;
+    unsigned* const err_word = st.cnt + 2 * gridDim.x;
+
+    const Float kappa = (Float)a.kappa[inst];
+    const Float delta = (Float)a.delta;
+    const Float theta = (Float)a.theta;
+    const Float obj_amp = (Float)a.obj_amp;
+    const bool push = a.is_push != 0;
+
+    for (int i = tid; i < pb.m; i += T)
+        pi_s[i] = pig[i];
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        x_s[i] = xg[i];
+    for (int i = tid; i <= pb.rmax; i += T)
+        stale_s[i] = staleg[i];
+
+    MinStd rng;
+    rng.s = st.status[inst].rng; // meaningful in thread 0 only
+    const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
+    double alg_bytes = 0.0; // thread 0 only
+
+    if (tid == 0) {
+        misc_s[MS_PICH] = 0;
+        if (ord == 2 || ord == 7)
+            rng.shuffle(vlist, (unsigned)nrows);
+    }
+    __syncthreads();
+
+    // c_j - sum over column j of |a| * (pi + P), one accumulator, CSC order
+    // (local_compute_reduced_cost, :295-306); `pe` / `pown` substitute the
+    // row's own entry (not yet in HBM)
+    auto column_rc = [&](int j, int pe, Float pown) -> Float {
+        Float acc = 0;
+        const int q0 = pb.col_start[j];
+        const int qe = q0 + pb.col_len[j];
+        for (int q = q0; q < qe; ++q) {
+            const Float p = q == pe ? pown : P[q];
+            const Float fa = (Float)pb.col_fac[q];
+            acc += fa * (pi_s[pb.col_row[q]] + p);
+        }
+        return cost[j] - acc;
+    };
+
+    for (int it = 0; it < nrows; ++it) {
+        const int k = (ord == 1) ? vlist[nrows - 1 - it] : vlist[it];
+        const int rs = pb.row_ptr[k];
+        const int r = pb.row_ptr[k + 1] - rs;
+        const int zk = pb.zkind[k];
+
+        // ---- decrease_preference + compute_reduced_costs (+ push) ----------
+        for (int idx = tid; idx < r; idx += T) {
+            const int e = rs + idx;
+            const int j = pb.row_col[e];
+            const int pe = pb.row_pos[e];
+            Float v = column_rc(j, pe, P[pe] * theta);
+            if (push) // :467-469: the true column
+                v += obj_amp * cost[j];
+            val_s[idx] = v;
+        }
+        const int n2 = next_pow2(r < 2 ? 2 : r);
+        if (tid == 0)
+            misc_s[MS_TIE] = 0;
+        __syncthreads();
+
+        // ---- calculator_sort (every kind but the plain exhaustive one) -----
+        if (zk != Z_EXHAUSTIVE) {
+            for (int i = tid; i < n2; i += T) {
+                key_s[i] = i < r ? order_key<Float>(val_s[i], maximize) : ~0ull;
+                id_s[i] = i;
+            }
+            __syncthreads();
+            if (r > 1)
+                bitonic_sort(key_s, id_s, n2);
+            for (int i = tid; i + 1 < r; i += T)
+                if (key_s[i] == key_s[i + 1])
+                    misc_s[MS_TIE] = 1;
+            __syncthreads();
+            if (tid == 0 && misc_s[MS_TIE]) {
+                int b0 = 0;
+                for (int i = 1; i <= r; ++i) {
+                    if (i == r || key_s[i] != key_s[b0]) {
+                        rng.shuffle(id_s + b0, (unsigned)(i - b0));
+                        b0 = i;
+                    }
+                }
+            }
+        } else {
+            for (int i = tid; i < r; i += T)
+                id_s[i] = i;
+        }
+        __syncthreads();
+        for (int i = tid; i < r; i += T)
+            fz_s[i] = pb.fac32[rs + id_s[i]];
+        __syncthreads();
+
+        // ---- selection ------------------------------------------------------
+        const int bkmin = pb.bmin[k], bkmax = pb.bmax[k];
+        if (tid == 0) {
+            alg_bytes += pb.row_bytes[k];
+            int sel = -2;
+            if (zk == Z_LINEAR || zk == Z_UNCONSTRAINED_BB || zk == Z_UNCONSTRAINED_EXHAUSTIVE) {
+                // select_variables, :308-344 (reads R[i + 1] up to R[r])
+                auto Rv = [&](int i) -> Float { return i < r ? val_s[id_s[i]] : stale_s[i]; };
+                int sum = 0;
+                for (int i = -1; i < r; ++i) {
+                    if (bkmin <= sum && sum <= bkmax)
+                        sel = i;
+                    if (sel != -2) {
+                        const Float v = Rv(i + 1);
+                        // stop_iterating without an engine, itm-common.hpp:182-190
+                        if (maximize ? v < 0 : v > 0)
+                            break;
+                    }
+                    if (i + 1 < r)
+                        sum += fz_s[i + 1];
+                    // (i + 1 == r: the reference adds the stale R[r].f and leaves)
+                }
+            }
+            misc_s[MS_SEL] = sel;
+            misc_s[MS_SELMODE] = 0; // 1: B&B wanted, 2: exhaustive wanted
+            if (zk == Z_BB || (zk == Z_UNCONSTRAINED_BB && sel == -2))
+                misc_s[MS_SELMODE] = 1;
+            if (zk == Z_EXHAUSTIVE || (zk == Z_UNCONSTRAINED_EXHAUSTIVE && sel == -2))
+                misc_s[MS_SELMODE] = 2;
+        }
+        __syncthreads();
+        const int submode = misc_s[MS_SELMODE];
+        if (submode == 1) {
+            if (tid == 0) {
+                if (!bb_search<Float>(val_s, id_s, fz_s, r, bkmin, bkmax, maximize, scratch, res_s))
+                    __hip_atomic_store(err_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        } else if (submode == 2) {
+            // exhaustive_solver::solve, exhaustive-solver.hpp:185-252: the
+            // best of the row's precomputed feasible patterns, the first one
+            // among equals (one thread per pattern, sums in element order)
+            const int start = pb.ex_start[k], nsol = pb.ex_count[k];
+            if (tid == 0) {
+                key_s[0] = ~0ull;
+                misc_s[MS_CNT] = 0x7fffffff;
+            }
+            __syncthreads();
+            for (int t = tid; t < nsol; t += T) {
+                Float z = 0;
+                for (int jx = 0; jx < r; ++jx)
+                    if (pb.ex_flat[start + t * r + jx])
+                        z += val_s[id_s[jx]];
+                atomicMin(&key_s[0], order_key<Float>(z, maximize));
+            }
+            __syncthreads();
+            for (int t = tid; t < nsol; t += T) {
+                Float z = 0;
+                for (int jx = 0; jx < r; ++jx)
+                    if (pb.ex_flat[start + t * r + jx])
+                        z += val_s[id_s[jx]];
+                if (order_key<Float>(z, maximize) == key_s[0])
+                    atomicMin(&misc_s[MS_CNT], t);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const int best = misc_s[MS_CNT];
+                for (int i = 0; i < r; ++i)
+                    res_s[i] = pb.ex_flat[start + best * r + i] ? 1 : 0;
+            }
+            __syncthreads();
+        }
+        if (submode != 0) {
+            // both sub-solvers end with a sort by (result first, then value)
+            // and return the split index (:219-252, :505-533)
+            if (tid == 0) {
+                int* tmp = (int*)key_s; // ids in the new order
+                int cnt1 = 0;
+                if (submode == 1) { // R is sorted by value: a stable partition
+                    for (int i = 0; i < r; ++i)
+                        if (res_s[i])
+                            tmp[cnt1++] = id_s[i];
+                    int z0 = cnt1;
+                    for (int i = 0; i < r; ++i)
+                        if (!res_s[i])
+                            tmp[z0++] = id_s[i];
+                } else { // at most 9 items: libstdc++'s insertion sort
+                    for (int i = 0; i < r; ++i) {
+                        tmp[i] = id_s[i];
+                        tmp[r + i] = res_s[i];
+                        cnt1 += res_s[i];
+                    }
+                    auto less = [&](int ia, int ra, int ib, int rb) -> bool {
+                        if (ra == rb)
+                            return maximize ? val_s[ia] > val_s[ib] : val_s[ia] < val_s[ib];
+                        return ra > rb;
+                    };
+                    for (int i = 1; i < r; ++i) {
+                        const int vi = tmp[i], vr = tmp[r + i];
+                        int jx = i;
+                        while (jx > 0 && less(vi, vr, tmp[jx - 1], tmp[r + jx - 1])) {
+                            tmp[jx] = tmp[jx - 1];
+                            tmp[r + jx] = tmp[r + jx - 1];
+                            --jx;
+                        }
+                        tmp[jx] = vi;
+                        tmp[r + jx] = vr;
+                    }
+                }
+                for (int i = 0; i < r; ++i)
+                    id_s[i] = tmp[i];
+                misc_s[MS_SEL] = cnt1 == r ? r : cnt1 - 1;
+            }
+            __syncthreads();
+        }
+
+        // ---- local_affect, :346-439: pi and d first ----------------------------
+        if (tid == 0) {
+            const int sel = misc_s[MS_SEL];
+            auto Rv = [&](int i) -> Float { return i < r ? val_s[id_s[i]] : stale_s[i]; };
+            const Float one = 1, two = 2;
+            const Float middle = (two + one) / two;
+            const Float old_pi = pi_s[k];
+            Float new_pi;
+            if (sel < 0)
+                new_pi = old_pi + Rv(0) / two;
+            else if (sel + 1 >= r)
+                new_pi = old_pi + Rv(sel) * middle;
+            else
+                new_pi = old_pi + ((Rv(sel) + Rv(sel + 1)) / two);
+            pi_s[k] = new_pi;
+            if (signbit(old_pi) != signbit(new_pi))
+                misc_s[MS_PICH] = 1;
+            *d_s = (kappa / (one - kappa)) + delta;
+        }
+        __syncthreads();
+
+        // ---- every variable: x, P, then its repaired preference ------------
+        {
+            const int sel = misc_s[MS_SEL];
+            const Float d = *d_s;
+            for (int i = tid; i < r; i += T) {
+                const int idx = id_s[i];
+                const int e = rs + idx;
+                const int j = pb.row_col[e];
+                const int pe = pb.row_pos[e];
+                const bool up = sel < 0 ? false : (sel + 1 >= r ? true : i <= sel);
+                Float p = P[pe] * theta;
+                if (up) {
+                    atomicOr(&x_s[j >> 5], 1u << (j & 31));
+                    p = p + d;
+                    const Float repair = column_rc(j, pe, p);
+                    if (repair >= 0)
+                        p = p - repair + d;
+                } else {
+                    atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
+                    p = p - d;
+                    const Float repair = column_rc(j, pe, p);
+                    if (repair <= 0)
+                        p = p + repair - d;
+                }
+                P[pe] = p;
+            }
+        }
+        __syncthreads();
+        // R as the reference leaves it (values by final position)
+        for (int i = tid; i < r; i += T)
+            stale_s[i] = val_s[id_s[i]];
+        __syncthreads();
+    }
+
+    for (int i = tid; i < pb.m; i += T)
+        pig[i] = pi_s[i];
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        xg[i] = x_s[i];
+    for (int i = tid; i <= pb.rmax; i += T)
+        staleg[i] = stale_s[i];
+
+    const int cnt = rebuild_violated(
+      pb, x_s, st.vflag + (size_t)inst * pb.m, out_list, misc_s + MS_WAVES);
+
+    if (tid == 0) {
+        if (!keep)
+            st.vcount[inst] = cnt;
+        DevStatus s = st.status[inst];
+        s.remaining = cnt;
+        s.pi_changed = misc_s[MS_PICH];
+        s.rng = rng.s;
+        s.rows_in_sweep = (unsigned)nrows;
+        s.row_updates += (unsigned long long)nrows;
+        s.alg_bytes += alg_bytes;
+        st.status[inst] = s;
+    }
 }
 
 struct LdsPlan2

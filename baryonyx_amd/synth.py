@@ -228,6 +228,68 @@ def make_z(m, n, density, cost_kind="int", seed=5, kmax=5, short_rows=0.2) -> In
     )
 
 
+def make_zmix(m, n, cost_kind="int", seed=6, maxlen=14, maximize=True, kmax=5) -> Instance:
+    """Small rows covering every sub-solver choice of the Z solver
+    (itm-solver-inequalities-Z.cpp:125-187): -1/+1 rows (linear scan), rows
+    with general coefficients bounded on both sides (branch-and-bound from 10
+    elements, exhaustive below), equalities, and one-sided rows (the
+    `unconstrained` variants).  Every row has a feasible 0/1 assignment."""
+    rs = np.random.RandomState(seed)
+    rows, facs, cmin, cmax = [], [], [], []
+    for k in range(m):
+        t = k % 6
+        if t in (2, 5):
+            size = int(rs.randint(3, 10))
+        elif t == 0:
+            size = int(rs.randint(6, 21))
+        else:
+            size = int(rs.randint(10, maxlen + 1))
+        cols = np.sort(rs.choice(n, size=size, replace=False))
+        if t == 0:
+            f = rs.choice([-1, 1], size=size, p=[0.3, 0.7]).astype(np.int32)
+        else:
+            f = rs.randint(1, kmax + 1, size=size).astype(np.int32)
+            f[rs.random_sample(size) < 0.2] *= -1
+            if np.abs(f).max() < 2:
+                f[0] = 2 if f[0] > 0 else -2
+        lower = int(f[f < 0].sum())
+        upper = int(f[f > 0].sum())
+        pick = rs.random_sample(size) < 0.5
+        ssum = int(f[pick].sum())  # reachable activity
+        if t == 0:
+            lo, hi = INT_MIN, max(ssum, lower + 1)
+        elif t in (1, 2):
+            lo, hi = ssum - 1, ssum + 2
+            lo = max(lo, lower + 1)
+            hi = min(hi, upper - 1)
+            if lo > hi or not (lo <= ssum <= hi):
+                lo = hi = ssum
+        elif t == 3:
+            lo = hi = ssum
+        else:
+            lo, hi = INT_MIN, max(ssum, lower)
+        rows.append(cols)
+        facs.append(f)
+        cmin.append(lo)
+        cmax.append(hi)
+    row_ptr, col = _rows_to_csr(rows, n)
+    c = _costs(rs, n, cost_kind)
+    return Instance(
+        m=m,
+        n=n,
+        row_ptr=row_ptr,
+        col=col,
+        factor=np.concatenate(facs).astype(np.int32),
+        cmin=np.asarray(cmin, np.int64).clip(INT_MIN, None).astype(np.int32),
+        cmax=np.asarray(cmax, np.int32),
+        obj_var=np.arange(n, dtype=np.int32),
+        obj_factor=c,
+        maximize=maximize,
+        kind=4,
+        name=f"zmix-{m}x{n}-{cost_kind}-s{seed}",
+    )
+
+
 # BASELINE.json configs (SURVEY 8(d)): C1 scp41-shaped, C2 scpnrh1-shaped,
 # C3 aa04-shaped.
 def config_c1(cost_kind="int"):

@@ -122,8 +122,11 @@ typedef struct bxh_status
 
 const char* bxh_last_error(void);
 
-/* Solver constructors (e.g. itm-solver-inequalities-01.cpp:72-107), `batch`
- * of them, on HIP device `device`. P and pi start at zero, x at zero. */
+/* Solver constructors (e.g. itm-solver-inequalities-01.cpp:72-107;
+ * itm-solver-inequalities-Z.cpp:125-187 including the choice of the row
+ * sub-solvers and exhaustive_solver::build_constraints,
+ * exhaustive-solver.hpp:111-167), `batch` of them, on HIP device `device`.
+ * P and pi start at zero, x at zero. */
 int bxh_create(const bxh_problem* pb,
                int kind,
                int float_type,
@@ -191,7 +194,8 @@ int bxh_status_sync(bxh_handle h, bxh_status* status_batch);
 int bxh_kernel_time(bxh_handle h, double* total_ms, uint64_t* launches, int reset);
 
 /* Algorithmic bytes of one row update of row k:
- * sum_{j in row k} c_j (4 + 2F) + r_k (4 + 5F) + 2F + ceil(r_k / 8) 2,
+ * sum_{j in row k} c_j (4 + 2F) + r_k (4 + 5F) + 2F + ceil(r_k / 8) 2
+ * (inequalities-Z: twice the first term for the repair pass, + 4 r_k),
  * summed over the rows of the last sweep per instance is reported by bench.py;
  * this returns the per-row table so the host can do that sum. */
 int bxh_row_bytes(bxh_handle h, double* bytes_m);

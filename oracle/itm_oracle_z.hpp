@@ -169,6 +169,18 @@ struct BranchAndBound
     Float lower_bound;
     int b_min, b_max;
     bool maximize;
+    // SORT_CANONICAL: both sorts below are stable (ties keep their position),
+    // the rule the HIP path implements; SORT_STD: std::sort as the reference
+    int sort_mode = SORT_STD;
+
+    template<typename It, typename Cmp>
+    void do_sort(It b, It e, Cmp cmp)
+    {
+        if (sort_mode == SORT_STD)
+            std::sort(b, e, cmp);
+        else
+            std::stable_sort(b, e, cmp);
+    }
 
     Float init_z() const noexcept
     {
@@ -303,12 +315,12 @@ struct BranchAndBound
         // item::operator<, :212-220: both sides are divided by the LEFT
         // item's factor.
         if (maximize)
-            std::sort(items.begin(), items.end(), [](const Item& a, const Item& o) {
+            do_sort(items.begin(), items.end(), [](const Item& a, const Item& o) {
                 return (o.r / static_cast<Float>(a.factor)) <
                        (a.r / static_cast<Float>(a.factor));
             });
         else
-            std::sort(items.begin(), items.end(), [](const Item& a, const Item& o) {
+            do_sort(items.begin(), items.end(), [](const Item& a, const Item& o) {
                 return (a.r / static_cast<Float>(a.factor)) <
                        (o.r / static_cast<Float>(a.factor));
             });
@@ -335,7 +347,7 @@ struct BranchAndBound
                 items[i].result = solution[i] == 0 ? 1 : 0;
         }
 
-        std::sort(items.begin(),
+        do_sort(items.begin(),
                   items.end(),
                   [maximize_](const Item& l, const Item& r) {
                       if (l.result == r.result)
@@ -369,6 +381,7 @@ struct ZSubSolvers
     // Sub-solver choice per row, inequalities-Z.cpp:125-187.
     explicit ZSubSolvers(Solver<Float>& s)
     {
+        bb.sort_mode = s.sort_mode;
         const auto& cs = s.cs;
         s.Z.assign(static_cast<size_t>(s.m), Z_LINEAR);
         for (int k = 0; k != s.m; ++k) {

@@ -70,3 +70,34 @@ def test_optimize_bounded_budget(tmp_path):
     assert res.status == 0 and res.valid == 1 and res.remaining_constraints == 0
     assert res.value == res.recomputed_value
     assert res.value <= solve_res.value
+
+
+Z_SOLVE = [
+    ("knapsack-int", lambda: synth.make_z(20, 60, 0.2, "int", 21)),
+    ("knapsack-real", lambda: synth.make_z(30, 80, 0.15, "real", 22)),
+    ("zmix", lambda: synth.make_zmix(12, 60, "int", 23, maxlen=11, maximize=True)),
+    ("zmix-hard", lambda: synth.make_zmix(24, 60, "int", 21, maxlen=12, maximize=False)),
+]
+
+
+@pytest.mark.parametrize("name,maker", Z_SOLVE, ids=[c[0] for c in Z_SOLVE])
+def test_solve_general_coefficients_matches_oracle(oracle, tmp_path, name, maker):
+    """A problem with general integer coefficients goes to the inequalities-Z
+    solver (itm.hpp:108-109): LP file -> merged constraints -> HIP sweeps must
+    end where the CPU oracle's solve() ends (the last case runs into the
+    iteration limit on both sides)."""
+    path = str(tmp_path / "z.lp")
+    synth.write_lp(maker(), path)
+    inst = H.merged(path)
+    assert inst.kind == 4
+    params = dict(seed=987654321, limit=1000, theta=0.5, delta=0.01, kappa_step=1e-3, kappa_max=0.9,
+                  alpha=1.0, w=20.0, pushes_limit=3, pushing_iteration_limit=10)
+    res, x = H.run(path, 0, H.default_params(**params))
+    ores, oxw = oracle.solve(inst, 1, oracle.default_params(sort_mode=1, **params))
+    assert ores.status == res.status
+    if name != "zmix-hard":
+        assert res.status == 0
+    if res.status == 0:
+        assert res.valid == 1
+        assert ores.value == res.value
+        assert np.array_equal(pack_bits(x[: inst.n].astype(np.uint8)), oxw)

@@ -145,3 +145,24 @@ def test_pi_sign_change_needs_n_le_m(bxh):
     with pytest.raises(RuntimeError):
         dev.order_create(7)
     dev.close()
+
+
+Z_CASES = [
+    # (name, maker, float_type, maximize, order, x0_density)
+    ("zmix-int-max", lambda: synth.make_zmix(24, 60, "int", 6, maxlen=13, maximize=True), 1, True, 0, 0.0),
+    ("zmix-real-min", lambda: synth.make_zmix(24, 60, "real", 7, maxlen=13, maximize=False), 1, False, 0, 0.2),
+    ("zmix-int-f32", lambda: synth.make_zmix(30, 80, "int", 8, maxlen=12, maximize=True), 0, True, 2, 0.1),
+    ("zmix-real-rev", lambda: synth.make_zmix(30, 50, "real", 9, maxlen=12, maximize=False), 1, False, 1, 0.5),
+    ("zmix-infeas", lambda: synth.make_zmix(24, 60, "int", 10, maxlen=12, maximize=True), 1, True, 3, 0.3),
+    ("z-knapsack", lambda: synth.make_z(20, 60, 0.2, "int", 11), 1, True, 0, 0.0),
+    ("z-knapsack-real", lambda: synth.make_z(20, 60, 0.2, "real", 12), 1, True, 5, 0.3),
+]
+
+
+@pytest.mark.parametrize("case", Z_CASES, ids=[c[0] for c in Z_CASES])
+def test_z_sweeps_match_oracle(oracle, bxh, case):
+    """inequalities-Z (general integer coefficients): linear scan, branch and
+    bound, exhaustive patterns and their `unconstrained` variants, followed by
+    local_affect's repair pass (itm-solver-inequalities-Z.cpp:295-564)."""
+    _, maker, float_type, maximize, order, x0p = case
+    run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
