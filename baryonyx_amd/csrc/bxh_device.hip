@@ -1290,8 +1290,8 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
         if (int rc = bxh_order_create(h, a->order))
             return rc;
     for (int i = 0; i != h->batch; ++i)
-        if (!(a->kappa[i] >= 0.0 && a->kappa[i] < 1.0))
-            return fail(BXH_ERR_INVALID, "kappa must be in [0, 1)");
+        if (!(a->kappa[i] >= 0.0)) // (the reference lets kappa pass 1 when kappa_max does)
+            return fail(BXH_ERR_INVALID, "kappa must not be negative");
     HIP_TRY(hipSetDevice(h->device));
 
     // the pinned staging buffers are reused by the next call: wait for the

@@ -125,15 +125,21 @@ context_register(const context_ptr& ctx,
     }
 }
 
-// The unit-propagation preprocessor (lib/src/preprocessor.cpp) is a "next" row
-// of the scope table: both options currently hand the raw problem over
-// unchanged, i.e. preprocessor_options::none behaviour.
+// lpcore.cpp:85-96: the preprocessor runs unless the parameters say `none`
+static problem
+prepared(const context& ctx, const raw_problem& rawpb)
+{
+    return ctx.parameters.preprocessor == solver_parameters::preprocessor_options::all
+             ? preprocess(ctx, rawpb)
+             : unpreprocess(ctx, rawpb);
+}
+
 result
 solve(const context_ptr& ctx, const raw_problem& rawpb)
 {
     if (!ctx)
         return result{ result_status::empty_context };
-    return itm::solve(*ctx, unpreprocess(*ctx, rawpb));
+    return itm::solve(*ctx, prepared(*ctx, rawpb));
 }
 
 result
@@ -143,7 +149,7 @@ optimize(const context_ptr& ctx, const raw_problem& rawpb)
         return result{ result_status::empty_context };
     // the branch / nlopt / manual meta-optimisers wrap this call in the
     // reference (lpcore.cpp:100-132); they are host code outside the path
-    return itm::optimize(*ctx, unpreprocess(*ctx, rawpb));
+    return itm::optimize(*ctx, prepared(*ctx, rawpb));
 }
 
 // `name=value` lines, as the reference writes its .sol files

@@ -20,6 +20,7 @@ struct bxc_params
     int order, float_type, init_policy, cost_norm, pre_order;
     int device;
     long long sweep_budget;
+    int preprocessor; // solver_parameters::preprocessor_options: 0 none, 1 all
 };
 
 struct bxc_problem_info
@@ -65,6 +66,7 @@ bxc_default_params(bxc_params* p)
     p->init_policy = static_cast<int>(d.init_policy);
     p->cost_norm = static_cast<int>(d.cost_norm);
     p->pre_order = static_cast<int>(d.pre_order);
+    p->preprocessor = static_cast<int>(d.preprocessor);
 }
 
 static context_ptr
@@ -94,6 +96,7 @@ make_ctx(const bxc_params* p)
     q.init_policy = static_cast<solver_parameters::init_policy_type>(p->init_policy);
     q.cost_norm = static_cast<solver_parameters::cost_norm_type>(p->cost_norm);
     q.pre_order = static_cast<solver_parameters::pre_constraint_order>(p->pre_order);
+    q.preprocessor = static_cast<solver_parameters::preprocessor_options>(p->preprocessor);
     context_set_solver_parameters(ctx, q);
     context_set_parameters(ctx, "device", std::to_string(p->device));
     if (p->sweep_budget > 0)
@@ -133,6 +136,7 @@ bxc_parse(const char* path, bxc_problem_info* info)
 BX_EXPORT int
 bxc_merged(const char* path,
            int pre_order,
+           int preprocessor,
            int* m,
            int* n,
            int* nnz,
@@ -155,7 +159,7 @@ bxc_merged(const char* path,
     const raw_problem raw = make_problem(ctx, path);
     if (!raw)
         return -1;
-    const problem pb(raw);
+    const problem pb = preprocessor ? preprocess(*ctx, raw) : problem(raw);
     std::vector<merged_constraint> csts;
     try {
         csts = make_merged_constraints(*ctx, pb);
@@ -229,6 +233,85 @@ bxc_run(const char* path, int mode, const bxc_params* p, bxc_result* out, signed
     } catch (const std::exception& e) {
         std::snprintf(err, static_cast<size_t>(errlen), "%s", e.what());
         return -3;
+    }
+}
+
+// baryonyx::preprocess / affect / split on a file (lib/test/preprocess.cpp):
+// sizes of the reduced problem and, optionally, its objective.
+struct bxc_pp_info
+{
+    int variables, affected, equal, greater, less, n_objective, n_quadratic, problem_type;
+    double objective_constant;
+};
+
+static void
+pp_fill(const problem& pb, bxc_pp_info* o)
+{
+    o->variables = static_cast<int>(pb.vars.names.size());
+    o->affected = static_cast<int>(pb.affected_vars.names.size());
+    o->equal = static_cast<int>(pb.equal_constraints.size());
+    o->greater = static_cast<int>(pb.greater_constraints.size());
+    o->less = static_cast<int>(pb.less_constraints.size());
+    o->n_objective = static_cast<int>(pb.objective.elements.size());
+    o->n_quadratic = static_cast<int>(pb.objective.qelements.size());
+    o->problem_type = static_cast<int>(pb.problem_type);
+    o->objective_constant = pb.objective.value;
+}
+
+// `fix_zero` (may be null): name of a variable whose bounds are set to 0 = 0
+// before preprocessing.  `affect_var` >= 0: then affect() that variable of the
+// reduced problem to `affect_value` -> out_affect; `split_var` >= 0: split()
+// -> out_split1 (true) and out_split0 (false).
+BX_EXPORT int
+bxc_preprocess(const char* path,
+               const char* fix_zero,
+               bxc_pp_info* out,
+               int affect_var,
+               int affect_value,
+               bxc_pp_info* out_affect,
+               int split_var,
+               bxc_pp_info* out_split1,
+               bxc_pp_info* out_split0,
+               double* lin_factor,
+               int* lin_var,
+               double* quad_factor,
+               int* quad_a,
+               int* quad_b)
+{
+    try {
+        auto ctx = make_context(3);
+        raw_problem raw = make_problem(ctx, path);
+        if (!raw)
+            return -1;
+        if (fix_zero)
+            for (size_t i = 0; i != raw.vars.names.size(); ++i)
+                if (raw.vars.names[i] == fix_zero) {
+                    raw.vars.values[i].min = 0;
+                    raw.vars.values[i].max = 0;
+                }
+        const problem pp = preprocess(*ctx, raw);
+        pp_fill(pp, out);
+        if (lin_factor)
+            for (size_t i = 0; i != pp.objective.elements.size(); ++i) {
+                lin_factor[i] = pp.objective.elements[i].factor;
+                lin_var[i] = pp.objective.elements[i].variable_index;
+            }
+        if (quad_factor)
+            for (size_t i = 0; i != pp.objective.qelements.size(); ++i) {
+                quad_factor[i] = pp.objective.qelements[i].factor;
+                quad_a[i] = pp.objective.qelements[i].variable_index_a;
+                quad_b[i] = pp.objective.qelements[i].variable_index_b;
+            }
+        if (affect_var >= 0 && out_affect)
+            pp_fill(affect(*ctx, pp, affect_var, affect_value != 0), out_affect);
+        if (split_var >= 0 && out_split1 && out_split0) {
+            const auto both = split(*ctx, pp, split_var);
+            pp_fill(std::get<0>(both), out_split1);
+            pp_fill(std::get<1>(both), out_split0);
+        }
+        return 0;
+    } catch (...) {
+        return -2;
     }
 }
 

@@ -12,6 +12,7 @@
 #include <istream>
 #include <random>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace baryonyx {
@@ -67,6 +68,10 @@ struct problem
 
 raw_problem make_problem(const context& ctx, std::istream& is) noexcept;
 problem unpreprocess(const context& ctx, const raw_problem& pb);
+// lib/src/preprocessor.cpp:866-913 (baryonyx_amd/host/preprocessor.cpp)
+problem preprocess(const context& ctx, const raw_problem& pb);
+problem affect(const context& ctx, const problem& pb, int variable_index, bool variable_value);
+std::tuple<problem, problem> split(const context& ctx, const problem& pb, int variable_index_to_affect);
 
 // One merged row b_min <= sum a x <= b_max (lib/src/itm-common.hpp:55-71).
 struct merged_constraint

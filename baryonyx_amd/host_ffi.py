@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST = os.path.join(_HERE, "host")
 LIB_PATH = os.path.join(HOST, "libbaryonyx_amd.so")
-SOURCES = ["lp_parser.cpp", "problem.cpp", "itm_gpu.cpp", "api.cpp", "c_api.cpp"]
+SOURCES = ["lp_parser.cpp", "problem.cpp", "preprocessor.cpp", "itm_gpu.cpp", "api.cpp", "c_api.cpp"]
 
 
 class Params(C.Structure):
@@ -23,13 +23,19 @@ class Params(C.Structure):
         ("pushes_limit", C.c_int), ("pushing_iteration_limit", C.c_int),
         ("init_population_size", C.c_int), ("order", C.c_int), ("float_type", C.c_int),
         ("init_policy", C.c_int), ("cost_norm", C.c_int), ("pre_order", C.c_int),
-        ("device", C.c_int), ("sweep_budget", C.c_longlong)]
+        ("device", C.c_int), ("sweep_budget", C.c_longlong), ("preprocessor", C.c_int)]
 
 
 class ProblemInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "status variables equal greater less nnz maximize problem_type n_objective "
         "n_quadratic n_binary").split()] + [("objective_constant", C.c_double)]
+
+
+class PreprocessInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "variables affected equal greater less n_objective n_quadratic problem_type").split()] + [
+        ("objective_constant", C.c_double)]
 
 
 class Result(C.Structure):
@@ -67,7 +73,10 @@ def lib():
         L.bxc_default_params.argtypes = [C.POINTER(Params)]
         L.bxc_parse.argtypes = [C.c_char_p, C.POINTER(ProblemInfo)]
         ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
-        L.bxc_merged.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, dp, dp, ip, ip]
+        L.bxc_merged.argtypes = [C.c_char_p, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, dp, dp, ip, ip]
+        L.bxc_preprocess.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PreprocessInfo), C.c_int, C.c_int,
+                                     C.POINTER(PreprocessInfo), C.c_int, C.POINTER(PreprocessInfo),
+                                     C.POINTER(PreprocessInfo), dp, ip, dp, ip, ip]
         L.bxc_run.argtypes = [C.c_char_p, C.c_int, C.POINTER(Params), C.POINTER(Result),
                               C.POINTER(C.c_byte), C.c_char_p, C.c_int]
         _LIB = L
@@ -90,15 +99,17 @@ def parse(path) -> ProblemInfo:
     return info
 
 
-def merged(path, pre_order=0):
+def merged(path, pre_order=0, preprocessor=1):
     """The merged constraints + linear objective of an LP file as a
-    baryonyx_amd.synth.Instance (what a Solver constructor receives)."""
+    baryonyx_amd.synth.Instance (what a Solver constructor receives);
+    `preprocessor` as solver_parameters::preprocessor_options (1 = all, the
+    default of solve / optimize)."""
     from .synth import Instance
 
     L = lib()
     m, n, nnz, nobj, mx, pt = (C.c_int() for _ in range(6))
     const = C.c_double()
-    rc = L.bxc_merged(os.fsencode(path), pre_order, m, n, nnz, nobj, None, None, None, None,
+    rc = L.bxc_merged(os.fsencode(path), pre_order, preprocessor, m, n, nnz, nobj, None, None, None, None,
                       None, None, None, C.byref(const), mx, pt)
     if rc != 0:
         raise RuntimeError(f"bxc_merged({path}) -> {rc}")
@@ -110,7 +121,7 @@ def merged(path, pre_order=0):
     ov = np.zeros(nobj.value, np.int32)
     of = np.zeros(nobj.value, np.float64)
     ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
-    rc = L.bxc_merged(os.fsencode(path), pre_order, m, n, nnz, nobj,
+    rc = L.bxc_merged(os.fsencode(path), pre_order, preprocessor, m, n, nnz, nobj,
                       row_ptr.ctypes.data_as(ip), col.ctypes.data_as(ip), fac.ctypes.data_as(ip),
                       cmin.ctypes.data_as(ip), cmax.ctypes.data_as(ip), ov.ctypes.data_as(ip),
                       of.ctypes.data_as(dp), C.byref(const), mx, pt)
@@ -135,3 +146,28 @@ def run(path, mode=0, params=None):
     if rc != 0:
         raise RuntimeError(err.value.decode())
     return res, x
+
+
+def preprocess(path, fix_zero=None, affect=None, split=None):
+    """baryonyx::preprocess on an LP file; returns a dict with the reduced
+    problem's sizes and objective, plus `affect` (var, value) / `split` (var)
+    results when asked (lib/src/preprocessor.cpp:866-913)."""
+    L = lib()
+    info, aff, s1, s0 = (PreprocessInfo() for _ in range(4))
+    raw = parse(path)
+    nlin = max(raw.n_objective + raw.n_quadratic, 1)
+    lf, lv = np.zeros(nlin, np.float64), np.zeros(nlin, np.int32)
+    nq = max(raw.n_quadratic, 1)
+    qf, qa, qb = np.zeros(nq, np.float64), np.zeros(nq, np.int32), np.zeros(nq, np.int32)
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    rc = L.bxc_preprocess(os.fsencode(path), None if fix_zero is None else fix_zero.encode(),
+                          C.byref(info), -1 if affect is None else affect[0],
+                          0 if affect is None else int(affect[1]), C.byref(aff),
+                          -1 if split is None else split, C.byref(s1), C.byref(s0),
+                          lf.ctypes.data_as(dp), lv.ctypes.data_as(ip), qf.ctypes.data_as(dp),
+                          qa.ctypes.data_as(ip), qb.ctypes.data_as(ip))
+    if rc != 0:
+        raise RuntimeError(f"bxc_preprocess({path}) -> {rc}")
+    return dict(info=info, affect=aff, split1=s1, split0=s0,
+                linear=[(int(lv[i]), float(lf[i])) for i in range(info.n_objective)],
+                quadratic=[(int(qa[i]), int(qb[i]), float(qf[i])) for i in range(info.n_quadratic)])

@@ -101,3 +101,4 @@ def test_solve_general_coefficients_matches_oracle(oracle, tmp_path, name, maker
         assert res.valid == 1
         assert ores.value == res.value
         assert np.array_equal(pack_bits(x[: inst.n].astype(np.uint8)), oxw)
+
