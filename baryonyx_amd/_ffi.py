@@ -176,7 +176,7 @@ class DeviceBatch:
     compute_order::run / push_and_run for every instance at once.
     """
 
-    def __init__(self, inst, cost, batch, kind=None, float_type=1, maximize=None, device=0):
+    def __init__(self, inst, cost, batch, kind=None, float_type=1, maximize=None, device=0, qcost=None):
         self.L = lib()
         self.inst = inst
         self.batch = int(batch)
@@ -192,11 +192,18 @@ class DeviceBatch:
         )
         k = self._keep
         assert k["cost"].shape[0] == inst.n
+        nq, qp, qi, qf = 0, None, None, None
+        if qcost is not None:  # (q_ptr, q_id, q_factor): quadratic_cost_type's adjacency
+            k["q_ptr"] = np.ascontiguousarray(qcost[0], np.int32)
+            k["q_id"] = np.ascontiguousarray(qcost[1], np.int32)
+            k["q_factor"] = np.ascontiguousarray(qcost[2], np.float64)
+            nq = int(k["q_id"].shape[0])
+            qp, qi, qf = _p(k["q_ptr"], i32p), _p(k["q_id"], i32p), _p(k["q_factor"], f64p)
         pb = BxhProblem(
             inst.m, inst.n, inst.nnz,
             _p(k["row_ptr"], i32p), _p(k["col"], i32p), _p(k["factor"], i32p),
             _p(k["cmin"], i32p), _p(k["cmax"], i32p), _p(k["cost"], f64p),
-            0, None, None, None,
+            nq, qp, qi, qf,
         )
         h = C.c_void_p()
         _check(self.L.bxh_create(C.byref(pb), self.kind, float_type, int(self.maximize),

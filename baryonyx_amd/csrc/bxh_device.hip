@@ -117,6 +117,8 @@ struct bxh_handle_s
     DevBuf<int2> mlist, mtmp;
     // inequalities-Z
     DevBuf<int> fac32, col_fac, ex_start, ex_count, ex_flat;
+    DevBuf<int> q_ptr, q_id;            // quadratic objective
+    DevBuf<unsigned char> q_factor;
     DevBuf<signed char> zkind;
     DevBuf<unsigned char> zscratch;
     DevBuf<int> mcount, mrun, slist, vamt, sid;
@@ -324,9 +326,15 @@ bxh_create(const bxh_problem* pb,
         return fail(BXH_ERR_UNSUPPORTED,
                     "only float and double exist on the device (long double "
                     "does not)");
-    if (pb->n_quad != 0)
-        return fail(BXH_ERR_UNSUPPORTED,
-                    "quadratic objective terms are not on the device yet");
+    if (pb->n_quad < 0 || (pb->n_quad > 0 && (!pb->q_ptr || !pb->q_id || !pb->q_factor)))
+        return fail(BXH_ERR_INVALID, "quadratic objective arrays");
+    if (pb->n_quad > 0) {
+        if (pb->q_ptr[0] != 0 || pb->q_ptr[pb->n] != pb->n_quad)
+            return fail(BXH_ERR_INVALID, "q_ptr does not span the quadratic terms");
+        for (int i = 0; i != pb->n_quad; ++i)
+            if (pb->q_id[i] < 0 || pb->q_id[i] >= pb->n)
+                return fail(BXH_ERR_INVALID, "quadratic partner out of range");
+    }
     if (pb->nnz > 0x7fffffffLL)
         return fail(BXH_ERR_UNSUPPORTED, "more than 2^31-1 elements");
     if (pb->row_ptr[0] != 0 || pb->row_ptr[pb->m] != pb->nnz)
@@ -405,6 +413,8 @@ bxh_create(const bxh_problem* pb,
                 groups = g;
         }
     }
+    if (pb->n_quad > 0) // c(j, x) reads every x bit: one owner
+        groups = 1;
     h->groups = groups;
 
     // Column owners.  Every owner should hold about r_k / groups entries of
@@ -761,6 +771,16 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->bmax.upload(bmax));
     HIP_TRY(h->bneg.upload(bneg));
     HIP_TRY(h->fac_csr.upload(fac_csr));
+    if (pb->n_quad > 0) {
+        HIP_TRY(h->q_ptr.upload(std::vector<int>(pb->q_ptr, pb->q_ptr + n + 1)));
+        HIP_TRY(h->q_id.upload(std::vector<int>(pb->q_id, pb->q_id + pb->n_quad)));
+        std::vector<unsigned char> qf;
+        if (float_type == BXH_FLOAT)
+            to_float<float>(pb->q_factor, static_cast<size_t>(pb->n_quad), qf);
+        else
+            to_float<double>(pb->q_factor, static_cast<size_t>(pb->n_quad), qf);
+        HIP_TRY(h->q_factor.upload(qf));
+    }
     if (zsolver) {
         if (ex_flat.empty())
             ex_flat.push_back(0);
@@ -971,6 +991,9 @@ bxh_create(const bxh_problem* pb,
     dp.bmax = h->bmax.p;
     dp.bneg = h->bneg.p;
     dp.cost = h->cost.p;
+    dp.q_ptr = pb->n_quad > 0 ? h->q_ptr.p : nullptr;
+    dp.q_id = h->q_id.p;
+    dp.q_factor = h->q_factor.p;
     dp.row_bytes = h->row_bytes.p;
 
     bxh::DevState& ds = h->ds;

@@ -60,7 +60,12 @@ struct DevProblem
     const int* bmin;           // [m] clamped as the Solver constructor does
     const int* bmax;           // [m]
     const int* bneg;           // [m] negative_factor (== c_size of the row)
-    const void* cost;          // [n] Float
+    const void* cost;          // [n] Float (linear part)
+    // quadratic_cost_type (itm-common.hpp:1150-1440): partners of variable j are
+    // q_id[q_ptr[j] .. q_ptr[j+1]); null when the objective is linear
+    const int* q_ptr;          // [n+1]
+    const int* q_id;           // [n_quad]
+    const void* q_factor;      // [n_quad] Float
     const double* row_bytes;   // [m] algorithmic bytes of one update of row k
 };
 
@@ -239,6 +244,24 @@ order_key(Float v, bool maximize)
     unsigned long long b = (unsigned long long)__double_as_longlong(d);
     b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
     return maximize ? ~b : b;
+}
+
+// c(j, x) of quadratic_cost_type (itm-common.hpp:1413-1425): the linear cost
+// plus the factor of every quadratic partner whose x bit is set, in the
+// order of the adjacency list.  `lin` is the linear cost of j.
+template<typename Float>
+__device__ inline Float
+cost_x(const DevProblem& pb, const unsigned* x_s, int j, Float lin)
+{
+    if (pb.q_ptr) {
+        const Float* qf = (const Float*)pb.q_factor;
+        for (int f = pb.q_ptr[j], l = pb.q_ptr[j + 1]; f != l; ++f) {
+            const int o = pb.q_id[f];
+            if ((x_s[o >> 5] >> (o & 31)) & 1u)
+                lin += qf[f];
+        }
+    }
+    return lin;
 }
 
 // Inverse of order_key (the value's sign of zero is lost: +0.0 comes back,
@@ -1044,11 +1067,12 @@ sweep_kernel(DevProblem pb, DevState st, DevSweep a)
                     sum_a_p += p;
                 }
             }
-            Float v = cost[j] - sum_a_pi - sum_a_p;
+            const Float cj = cost_x<Float>(pb, x_s, j, cost[j]);
+            Float v = cj - sum_a_pi - sum_a_p;
             if (PM1 && pb.fac_csr[e] < 0)
                 v = -v;
             if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
-                v += obj_amp * (PM1 ? cost[j] : cost[idx]);
+                v += obj_amp * (PM1 ? cj : cost_x<Float>(pb, x_s, idx, cost[idx]));
             val_s[idx] = v;
         }
         const int n2 = next_pow2(r < 2 ? 2 : r);
@@ -1529,7 +1553,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
             const Float fa = (Float)pb.col_fac[q];
             acc += fa * (pi_s[pb.col_row[q]] + p);
         }
-        return cost[j] - acc;
+        return cost_x<Float>(pb, x_s, j, cost[j]) - acc;
     };
 
     for (int it = 0; it < nrows; ++it) {
@@ -1545,7 +1569,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
             const int pe = pb.row_pos[e];
             Float v = column_rc(j, pe, P[pe] * theta);
             if (push) // :467-469: the true column
-                v += obj_amp * cost[j];
+                v += obj_amp * cost_x<Float>(pb, x_s, j, cost[j]);
             val_s[idx] = v;
         }
         const int n2 = next_pow2(r < 2 ? 2 : r);
@@ -1725,7 +1749,10 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         {
             const int sel = misc_s[MS_SEL];
             const Float d = *d_s;
-            for (int i = tid; i < r; i += T) {
+            // with a quadratic objective c(j, x) of a later variable sees the
+            // x bits set for the earlier ones: one thread, in R order
+            const bool serial = pb.q_ptr != nullptr;
+            for (int i = serial ? 0 : tid; i < (serial && tid != 0 ? 0 : r); i += serial ? 1 : T) {
                 const int idx = id_s[i];
                 const int e = rs + idx;
                 const int j = pb.row_col[e];
@@ -2290,11 +2317,13 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         for (int l = tid; l < ro; l += T) {
             const int idx = MW ? oidx_s[l] : l; // position in the whole row
             const int j = col_s[l];
-            Float v = cost_s[l] - spi_s[l] - sp_s[l];
+            // (a quadratic objective runs with one owner: x_s is complete)
+            const Float cj = cost_x<Float>(pb, x_s, j, cost_s[l]);
+            Float v = cj - spi_s[l] - sp_s[l];
             if (PM1 && pb.fac_csr[rs + idx] < 0)
                 v = -v;
             if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
-                v += obj_amp * (PM1 ? cost_s[l] : cost[idx]);
+                v += obj_amp * (PM1 ? cj : cost_x<Float>(pb, x_s, idx, cost[idx]));
             if (MW) {
                 const unsigned long long bits =
                   (unsigned long long)__double_as_longlong((double)v);

@@ -150,7 +150,11 @@ bxc_merged(const char* path,
            double* obj_factor,
            double* obj_constant,
            int* maximize,
-           int* problem_type)
+           int* problem_type,
+           int* n_quad,
+           int* quad_a,
+           int* quad_b,
+           double* quad_factor)
 {
     auto ctx = make_context(3);
     solver_parameters q;
@@ -176,8 +180,16 @@ bxc_merged(const char* path,
     *obj_constant = pb.objective.value;
     *maximize = pb.type == objective_function_type::maximize;
     *problem_type = static_cast<int>(pb.problem_type);
+    if (n_quad)
+        *n_quad = static_cast<int>(pb.objective.qelements.size());
     if (!row_ptr)
         return 0;
+    if (quad_a)
+        for (size_t i = 0; i != pb.objective.qelements.size(); ++i) {
+            quad_a[i] = pb.objective.qelements[i].variable_index_a;
+            quad_b[i] = pb.objective.qelements[i].variable_index_b;
+            quad_factor[i] = pb.objective.qelements[i].factor;
+        }
     int e = 0;
     row_ptr[0] = 0;
     for (int k = 0; k != *m; ++k) {

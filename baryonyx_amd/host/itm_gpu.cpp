@@ -69,6 +69,10 @@ struct cost_type
     const objective_function& obj;
     int n;
     std::vector<Float> linear;
+    // quadratic_cost_type (itm-common.hpp:1150-1209): for every variable the
+    // partners it shares a quadratic term with, in term order
+    std::vector<int> q_ptr, q_id;
+    std::vector<Float> q_factor;
 
     cost_type(const objective_function& o, int n_)
       : obj(o)
@@ -77,9 +81,32 @@ struct cost_type
     {
         for (const auto& e : o.elements)
             linear[e.variable_index] += static_cast<Float>(e.factor);
+        if (!o.qelements.empty()) {
+            q_ptr.assign(static_cast<size_t>(n) + 1, 0);
+            for (int v = 0; v != n; ++v) {
+                q_ptr[v + 1] = q_ptr[v];
+                for (const auto& q : o.qelements)
+                    if (q.variable_index_a == v || q.variable_index_b == v) {
+                        q_id.push_back(q.variable_index_a == v ? q.variable_index_b
+                                                               : q.variable_index_a);
+                        q_factor.push_back(static_cast<Float>(q.factor));
+                        ++q_ptr[v + 1];
+                    }
+            }
+        }
     }
 
-    Float operator[](int i) const noexcept { return linear[i]; }
+    bool quadratic() const noexcept { return !q_ptr.empty(); }
+
+    // itm-common.hpp:1129-1132 / :1400-1411
+    Float operator[](int i) const noexcept
+    {
+        Float ret = linear[i];
+        if (quadratic())
+            for (int f = q_ptr[i], l = q_ptr[i + 1]; f != l; ++f)
+                ret += q_factor[f];
+        return ret;
+    }
 
     double results(const bit_array& x, double constant) const noexcept
     {
@@ -92,10 +119,13 @@ struct cost_type
         return constant;
     }
 
-    Float min_abs() const noexcept
+    Float min_abs() const noexcept // :1091-1101 / :1328-1341
     {
         Float mn = std::numeric_limits<Float>::max();
         for (auto v : linear)
+            if (v)
+                mn = std::min(mn, std::abs(v));
+        for (auto v : q_factor)
             if (v)
                 mn = std::min(mn, std::abs(v));
         return mn;
@@ -108,25 +138,36 @@ struct cost_type
         switch (norm) {
         case nt::none:
             return;
-        case nt::l1:
+        case nt::l1: // :1343-1360
             for (auto v : linear)
                 div += std::abs(v);
+            for (auto v : q_factor)
+                div += std::abs(v);
             break;
-        case nt::l2: // sum of squares, no square root (itm-common.hpp:1107-1117)
+        case nt::l2: // sum of squares, no square root (itm-common.hpp:1107-1117, :1362-1380)
             for (auto v : linear)
                 div += v * v;
+            for (auto v : q_factor)
+                div += v * v;
             break;
-        case nt::random:
+        case nt::random: // only the linear part is spread (:1221-1326), then loo
             random_norm(rng);
             div = *std::max_element(linear.begin(), linear.end());
+            for (auto v : q_factor)
+                div = std::max(v, div);
             break;
-        default: // infinity norm: the largest element (itm-common.hpp:1119-1127)
+        default: // infinity norm: the largest element (itm-common.hpp:1119-1127, :1382-1398)
             div = *std::max_element(linear.begin(), linear.end());
+            for (auto v : q_factor)
+                div = std::max(v, div);
             break;
         }
-        if (std::isnormal(div))
+        if (std::isnormal(div)) {
             for (auto& v : linear)
                 v /= div;
+            for (auto& v : q_factor)
+                v /= div;
+        }
     }
 
 private:
@@ -333,7 +374,8 @@ struct device_batch
         }
         std::vector<double> cost(static_cast<size_t>(n));
         for (int i = 0; i != n; ++i)
-            cost[i] = static_cast<double>(norm_costs[i]);
+            cost[i] = static_cast<double>(norm_costs.linear[i]);
+        std::vector<double> qf(norm_costs.q_factor.begin(), norm_costs.q_factor.end());
         bxh_problem pb{};
         pb.m = m;
         pb.n = n;
@@ -344,6 +386,12 @@ struct device_batch
         pb.cmin = cmin.data();
         pb.cmax = cmax.data();
         pb.cost = cost.data();
+        if (norm_costs.quadratic()) {
+            pb.n_quad = static_cast<std::int32_t>(norm_costs.q_id.size());
+            pb.q_ptr = norm_costs.q_ptr.data();
+            pb.q_id = norm_costs.q_id.data();
+            pb.q_factor = qf.data();
+        }
         const int ft = sizeof(Float) == 4 ? BXH_FLOAT : BXH_DOUBLE;
         const int rc = bxh_create(&pb, kind, ft, maximize ? 1 : 0, batch, ctx.device, &h);
         if (rc == BXH_ERR_OOM)
@@ -445,8 +493,6 @@ solve_problem(const context& ctx, const problem& pb)
         ret.status = result_status::success;
         ret.solutions.resize(1);
         ret.solutions.back().value = pb.objective.value;
-    } else if (!pb.objective.qelements.empty()) {
-        throw solver_failure(solver_error_tag::no_solver_available);
     } else {
         random_engine rng(seed_of(ctx));
         const cost_type<Float> original_costs(pb.objective, variables);
@@ -885,9 +931,6 @@ optimize_problem(const context& ctx, const problem& pb)
         fill_result(r, pb, variables, 0);
         return r;
     }
-    if (!pb.objective.qelements.empty())
-        throw solver_failure(solver_error_tag::no_solver_available);
-
     const auto& p = ctx.parameters;
     const bool maximize = pb.type == objective_function_type::maximize;
     random_engine rng(seed_of(ctx));

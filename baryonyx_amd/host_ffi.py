@@ -73,7 +73,8 @@ def lib():
         L.bxc_default_params.argtypes = [C.POINTER(Params)]
         L.bxc_parse.argtypes = [C.c_char_p, C.POINTER(ProblemInfo)]
         ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
-        L.bxc_merged.argtypes = [C.c_char_p, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, dp, dp, ip, ip]
+        L.bxc_merged.argtypes = [C.c_char_p, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, dp, dp, ip, ip,
+                                 ip, ip, ip, dp]
         L.bxc_preprocess.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PreprocessInfo), C.c_int, C.c_int,
                                      C.POINTER(PreprocessInfo), C.c_int, C.POINTER(PreprocessInfo),
                                      C.POINTER(PreprocessInfo), dp, ip, dp, ip, ip]
@@ -109,8 +110,9 @@ def merged(path, pre_order=0, preprocessor=1):
     L = lib()
     m, n, nnz, nobj, mx, pt = (C.c_int() for _ in range(6))
     const = C.c_double()
+    nq = C.c_int()
     rc = L.bxc_merged(os.fsencode(path), pre_order, preprocessor, m, n, nnz, nobj, None, None, None, None,
-                      None, None, None, C.byref(const), mx, pt)
+                      None, None, None, C.byref(const), mx, pt, nq, None, None, None)
     if rc != 0:
         raise RuntimeError(f"bxc_merged({path}) -> {rc}")
     row_ptr = np.zeros(m.value + 1, np.int32)
@@ -120,16 +122,20 @@ def merged(path, pre_order=0, preprocessor=1):
     cmax = np.zeros(m.value, np.int32)
     ov = np.zeros(nobj.value, np.int32)
     of = np.zeros(nobj.value, np.float64)
+    qa, qb = np.zeros(nq.value, np.int32), np.zeros(nq.value, np.int32)
+    qf = np.zeros(nq.value, np.float64)
     ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
     rc = L.bxc_merged(os.fsencode(path), pre_order, preprocessor, m, n, nnz, nobj,
                       row_ptr.ctypes.data_as(ip), col.ctypes.data_as(ip), fac.ctypes.data_as(ip),
                       cmin.ctypes.data_as(ip), cmax.ctypes.data_as(ip), ov.ctypes.data_as(ip),
-                      of.ctypes.data_as(dp), C.byref(const), mx, pt)
+                      of.ctypes.data_as(dp), C.byref(const), mx, pt, nq, qa.ctypes.data_as(ip),
+                      qb.ctypes.data_as(ip), qf.ctypes.data_as(dp))
     assert rc == 0
     kind = {0: 0, 1: 2, 2: 4, 3: 1, 4: 3, 5: 4}[pt.value]  # problem_solver_type -> bxh_kind
     return Instance(m=m.value, n=n.value, row_ptr=row_ptr, col=col, factor=fac, cmin=cmin,
                     cmax=cmax, obj_var=ov, obj_factor=of, obj_constant=const.value,
-                    maximize=bool(mx.value), kind=kind, name=os.path.basename(path))
+                    maximize=bool(mx.value), kind=kind, name=os.path.basename(path),
+                    q_a=qa, q_b=qb, q_factor=qf)
 
 
 def run(path, mode=0, params=None):

@@ -312,6 +312,13 @@ def write_lp(inst: Instance, path: str) -> None:
         terms = [f"{'+' if c >= 0 else '-'} {abs(c):.17g} x{j}" for j, c in zip(inst.obj_var, inst.obj_factor)]
         for i in range(0, len(terms), 8):
             f.write(" " + " ".join(terms[i : i + 8]) + "\n")
+        if len(inst.q_a):  # CPLEX-LP quadratic section: the bracket holds twice the factors
+            q = []
+            for a, b, c in zip(inst.q_a, inst.q_b, inst.q_factor):
+                c2 = 2.0 * float(c)
+                sign = "+" if c2 >= 0 else "-"
+                q.append(f"{sign} {abs(c2):.17g} x{a} ^ 2" if a == b else f"{sign} {abs(c2):.17g} x{a} * x{b}")
+            f.write(" + [ " + " ".join(q) + " ] / 2\n")
         f.write("subject to\n")
         for k in range(inst.m):
             s = slice(inst.row_ptr[k], inst.row_ptr[k + 1])

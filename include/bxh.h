@@ -88,7 +88,7 @@ typedef struct bxh_problem
     const int32_t* cmax;    /* [m] merged_constraint::max                   */
     const double* cost;     /* [n] normalised linear cost, already rounded
                                     to the device float kind                */
-    int32_t n_quad;         /* quadratic cost terms (must be 0 for now)     */
+    int32_t n_quad;         /* entries of quadratic_cost_type's adjacency   */
     const int32_t* q_ptr;   /* [n+1]   quadratic_cost_type::indices         */
     const int32_t* q_id;    /* [n_quad]                                     */
     const double* q_factor; /* [n_quad]                                     */

@@ -80,6 +80,7 @@ struct HandleBase
     virtual int rmax() = 0;
     virtual double compute_delta(double theta) = 0;
     virtual void get_cost(double* out) = 0;
+    virtual int get_qcost(std::int32_t* qptr, std::int32_t* qid, double* qfactor) = 0;
     virtual void get_x(std::uint64_t* w) = 0;
     virtual void set_x(const std::uint64_t* w) = 0;
     virtual void init_x(int policy, double random) = 0;
@@ -147,6 +148,20 @@ struct Handle : HandleBase
     {
         for (int i = 0; i != cs.n; ++i)
             out[i] = static_cast<double>(norm.linear[i]);
+    }
+    // the normalised quadratic part: adjacency of every variable
+    int get_qcost(std::int32_t* qptr, std::int32_t* qid, double* qfactor) override
+    {
+        const int count = norm.qsize();
+        if (qptr && norm.quadratic) {
+            for (int i = 0; i <= cs.n; ++i)
+                qptr[i] = norm.qindices[i];
+            for (int i = 0; i != count; ++i) {
+                qid[i] = norm.qid[i];
+                qfactor[i] = static_cast<double>(norm.qfactor[i]);
+            }
+        }
+        return count;
     }
     void get_x(std::uint64_t* w) override
     {
@@ -371,6 +386,11 @@ void
 orc_solver_get_cost(void* h, double* out)
 {
     H(h)->get_cost(out);
+}
+int
+orc_solver_get_qcost(void* h, int32_t* qptr, int32_t* qid, double* qfactor)
+{
+    return H(h)->get_qcost(qptr, qid, qfactor);
 }
 void
 orc_solver_get_x(void* h, uint64_t* w)

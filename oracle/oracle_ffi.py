@@ -109,6 +109,8 @@ def lib():
         L.orc_solver_compute_delta.argtypes = [C.c_void_p, C.c_double]
         L.orc_solver_compute_delta.restype = C.c_double
         L.orc_solver_get_cost.argtypes = [C.c_void_p, f64p]
+        L.orc_solver_get_qcost.argtypes = [C.c_void_p, i32p, i32p, f64p]
+        L.orc_solver_get_qcost.restype = C.c_int
         L.orc_solver_get_x.argtypes = [C.c_void_p, u64p]
         L.orc_solver_set_x.argtypes = [C.c_void_p, u64p]
         L.orc_solver_init_x.argtypes = [C.c_void_p, C.c_int, C.c_double]
@@ -227,6 +229,17 @@ class Solver:
         out = np.zeros(self.inst.n, np.float64)
         self.L.orc_solver_get_cost(self.h, _p(out, f64p))
         return out
+
+    def qcost(self):
+        """(q_ptr, q_id, q_factor) of the normalised quadratic costs, or None."""
+        cnt = self.L.orc_solver_get_qcost(self.h, None, None, None)
+        if cnt <= 0:
+            return None
+        qptr = np.zeros(self.inst.n + 1, np.int32)
+        qid = np.zeros(cnt, np.int32)
+        qf = np.zeros(cnt, np.float64)
+        self.L.orc_solver_get_qcost(self.h, _p(qptr, i32p), _p(qid, i32p), _p(qf, f64p))
+        return qptr, qid, qf
 
     def get_x(self):
         out = np.zeros(self.nwords, np.uint64)

@@ -102,3 +102,36 @@ def test_solve_general_coefficients_matches_oracle(oracle, tmp_path, name, maker
         assert ores.value == res.value
         assert np.array_equal(pack_bits(x[: inst.n].astype(np.uint8)), oxw)
 
+
+
+Q_SOLVE = [
+    ("scp", lambda: synth.make_scp(40, 200, 0.08, "int", 31), 150),
+    ("pm1", lambda: synth.make_pm1(40, 200, 0.08, "real", 32), 120),
+    ("knapsack", lambda: synth.make_z(20, 60, 0.2, "int", 33), 60),
+]
+
+
+@pytest.mark.parametrize("name,maker,terms", Q_SOLVE, ids=[c[0] for c in Q_SOLVE])
+def test_solve_quadratic_objective_matches_oracle(oracle, tmp_path, name, maker, terms):
+    """A quadratic objective goes through quadratic_cost_type
+    (itm-common.hpp:1150-1440): LP file with a `[ ... ] / 2` section -> HIP
+    sweeps == the CPU oracle's solve()."""
+    inst0 = maker()
+    rs = np.random.RandomState(99)
+    inst0.q_a = rs.randint(0, inst0.n, size=terms).astype(np.int32)
+    inst0.q_b = rs.randint(0, inst0.n, size=terms).astype(np.int32)
+    inst0.q_b[::5] = inst0.q_a[::5]
+    inst0.q_factor = rs.randint(-20, 21, size=terms).astype(np.float64) / 2.0
+    path = str(tmp_path / "q.lp")
+    synth.write_lp(inst0, path)
+    assert H.parse(path).n_quadratic > 0
+    inst = H.merged(path)
+    assert len(inst.q_a) == H.parse(path).n_quadratic or len(inst.q_a) > 0
+    params = dict(seed=13579, limit=500, theta=0.5, delta=0.01, kappa_step=1e-3, kappa_max=0.9,
+                  alpha=1.0, w=20.0, pushes_limit=3, pushing_iteration_limit=10)
+    res, x = H.run(path, 0, H.default_params(**params))
+    ores, oxw = oracle.solve(inst, 1, oracle.default_params(sort_mode=1, **params))
+    assert ores.status == res.status == 0
+    assert res.valid == 1
+    assert ores.value == res.value == res.recomputed_value
+    assert np.array_equal(pack_bits(x[: inst.n].astype(np.uint8)), oxw)

@@ -38,7 +38,8 @@ def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweep
         orcs.append(s)
     cost = orcs[0].cost()
     delta = orcs[0].compute_delta(theta)
-    dev = bxh.DeviceBatch(inst, cost, batch, float_type=float_type, maximize=maximize)
+    dev = bxh.DeviceBatch(inst, cost, batch, float_type=float_type, maximize=maximize,
+                          qcost=orcs[0].qcost())
     assert dev.rmax == orcs[0].rmax
 
     for b, s in enumerate(orcs):
@@ -166,3 +167,44 @@ def test_z_sweeps_match_oracle(oracle, bxh, case):
     local_affect's repair pass (itm-solver-inequalities-Z.cpp:295-564)."""
     _, maker, float_type, maximize, order, x0p = case
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
+
+
+def with_quadratic(inst, seed, terms):
+    """Add `terms` random quadratic objective terms f * x_a * x_b (some
+    squares) to an instance."""
+    rs = np.random.RandomState(seed)
+    a = rs.randint(0, inst.n, size=terms).astype(np.int32)
+    b = rs.randint(0, inst.n, size=terms).astype(np.int32)
+    b[::7] = a[::7]
+    inst.q_a, inst.q_b = a, b
+    inst.q_factor = np.round(rs.uniform(-20, 20, size=terms), 1)
+    return inst
+
+
+Q_CASES = [
+    # (name, maker, float_type, maximize, order, x0_density)
+    ("q-scp-int", lambda: with_quadratic(synth.make_scp(60, 400, 0.06, "int", 61), 1, 300), 1, False, 0, 0.1),
+    ("q-scp-real-f32-max", lambda: with_quadratic(synth.make_scp(50, 300, 0.08, "real", 62), 2, 200), 0, True, 2, 0.3),
+    ("q-spp", lambda: with_quadratic(synth.make_spp(40, 300, 0.06, "int", 63), 3, 250), 1, False, 0, 0.05),
+    ("q-pm1-ineq", lambda: with_quadratic(synth.make_pm1(50, 250, 0.06, "real", 64), 4, 200), 1, False, 1, 0.2),
+    ("q-pm1-eq", lambda: with_quadratic(synth.make_pm1(40, 250, 0.06, "int", 65, equalities=True), 5, 200), 1, True, 0, 0.2),
+    ("q-zmix", lambda: with_quadratic(synth.make_zmix(24, 60, "int", 66, maxlen=12, maximize=True), 6, 80), 1, True, 0, 0.2),
+    ("q-zmix-min", lambda: with_quadratic(synth.make_zmix(24, 60, "real", 67, maxlen=12, maximize=False), 7, 80), 1, False, 0, 0.4),
+]
+
+
+@pytest.mark.parametrize("case", Q_CASES, ids=[c[0] for c in Q_CASES])
+def test_quadratic_objective_matches_oracle(oracle, bxh, case, monkeypatch):
+    """quadratic_cost_type (itm-common.hpp:1150-1440): c(j, x) depends on the
+    current x in the reduced costs, in the push amplification and, for the Z
+    solver, in the repair pass (sequential there)."""
+    monkeypatch.delenv("BXH_FORCE_V1", raising=False)
+    _, maker, float_type, maximize, order, x0p = case
+    run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
+
+
+def test_quadratic_objective_lane_per_column_kernel(oracle, bxh, monkeypatch):
+    monkeypatch.setenv("BXH_FORCE_V1", "1")
+    for case in (Q_CASES[0], Q_CASES[3]):
+        _, maker, float_type, maximize, order, x0p = case
+        run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
