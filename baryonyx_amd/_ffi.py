@@ -122,7 +122,8 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
             )
-        L = C.CDLL(LIB_PATH)
+        # BXH_LIB: another build of the same C ABI (A/B timing of kernel variants)
+        L = C.CDLL(os.environ.get("BXH_LIB") or LIB_PATH)
         L.bxh_last_error.restype = C.c_char_p
         L.bxh_create.argtypes = [
             C.POINTER(BxhProblem), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -79,6 +79,7 @@ struct bxh_handle_s
     int version = 1;           // 1: lane-per-column walk, 2: staged column loads
     int nb = 0;                // v2: 16-entry pieces per staged column
     int groups = 1;            // v2: workgroups (column owners) per instance
+    int spare = 0;             // v2: spare staging slot set
     int romax = 0;             // longest per-owner part of a row
     unsigned epoch = 0;        // sweep launches so far (tags of the row exchange)
 
@@ -730,18 +731,22 @@ bxh_create(const bxh_problem* pb,
             tmax = std::min(tmax, 256);
             lds_cap = lds_limit / 2;
         }
-        for (int t = tmax; t >= 128; t >>= 1) {
-            const bxh::LdsPlan2 lp2 = bxh::lds_plan2(m, h->nwords, rmax, romax,
-                                                     static_cast<int>(h->fsize),
-                                                     (t / 64) * 16, np, groups > 1);
-            if (lp2.total <= lds_cap) {
-                h->version = 2;
-                h->nb = np;
-                h->threads = t;
-                h->lds_bytes = static_cast<size_t>(lp2.total);
-                break;
+        // a spare set of slots (the overflow chunk of a row, summed in the same
+        // pass as wave 0's own chunk) where it fits beside a full set of waves
+        for (int t = tmax; t >= 128 && h->version != 2; t >>= 1)
+            for (int spare = 1; spare >= 0; --spare) {
+                const bxh::LdsPlan2 lp2 = bxh::lds_plan2(m, h->nwords, rmax, romax,
+                                                         static_cast<int>(h->fsize),
+                                                         (t / 64 + spare) * 16, np, groups > 1);
+                if (lp2.total <= lds_cap) {
+                    h->version = 2;
+                    h->nb = np;
+                    h->threads = t;
+                    h->spare = spare;
+                    h->lds_bytes = static_cast<size_t>(lp2.total);
+                    break;
+                }
             }
-        }
     }
     if (std::getenv("BXH_DEBUG"))
         std::fprintf(stderr, "bxh: kernel v%d threads=%d lds=%zu np=%d groups=%d\n", h->version,
@@ -962,6 +967,7 @@ bxh_create(const bxh_problem* pb,
     dp.nnzp = nnzp;
     dp.groups = groups;
     dp.romax = romax;
+    dp.spare = h->spare;
     dp.sub_ptr = h->sub_ptr.p;
     dp.sub_e = h->sub_e.p;
     dp.sub_desc = h->sub_desc.p;

@@ -29,6 +29,7 @@ struct DevProblem
     int nnzp;     // CSC slots of one owner's slice (columns padded to 16 entries)
     int groups;   // workgroups (column owners, column j -> j % groups) per instance
     int romax;    // longest per-owner part of a row
+    int spare;    // 1: a spare set of 16 staging slots exists (overflow chunk)
     int cmax;     // longest column (real entries)
     int kind;     // bxh_kind
     int maximize; // 0 / 1
@@ -1896,7 +1897,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         return;
 
     const int tid = threadIdx.x, T = blockDim.x;
-    const int G = (T >> 6) * 8 * LR; // staging slots: 8 * LR columns per wave
+    const int G = ((T >> 6) + pb.spare) * 8 * LR; // staging slots: 8 * LR columns per wave (+ a spare set)
     constexpr int SP = NP * 16 + 2; // Float entries of a P slot (16-byte rows)
     constexpr int SI = NP * 16 + 4; // 16-bit entries of an index slot (8-byte rows)
     typedef Float Float2 __attribute__((ext_vector_type(2)));
@@ -2142,6 +2143,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const int g8 = lane >> 3;
     Float* const wst_p = stg_p + wave * (CW * SP);
     unsigned short* const wst_i = stg_i + wave * (CW * SI);
+    // the spare set of slots behind those of the last wave (overflow chunk)
+    Float* const xst_p = stg_p + nwaves * (CW * SP);
+    unsigned short* const xst_i = stg_i + nwaves * (CW * SI);
     Float2 regP[LR][NP];
     unsigned regI[LR][NP]; // two 16-bit row indices per lane and piece
     const char* const Pb = reinterpret_cast<const char*>(P);
@@ -2206,19 +2210,26 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // each, strictly in CSC order
         // (itm-solver-inequalities-01.cpp:173-188); padding entries are +0.0
         // / pi_s[m] == +0.0 and leave the sums bit-identical.
+        // An owner's part of a row may exceed the 16 columns per wave (8
+        // waves: 128) by a few columns.  That overflow chunk is loaded by wave
+        // 0 behind its own chunk, staged in a spare set of slots, and summed
+        // by the wave's lanes 32-63 in the same pass as its own chunk -- not
+        // in a second pass of its own, which the whole workgroup (and the
+        // partners of the instance) would wait for.
         {
-            for (; chunk < nchunks; chunk += nwaves) {
+            const bool overflow = pb.spare && nchunks > nwaves; // chunk `nwaves` exists
+            auto stage = [&](Float* base_p, unsigned short* base_i, int chunk_, int npm_) {
 #pragma unroll
                 for (int h = 0; h < LR; ++h) {
-                    const int t = chunk * CW + h * 8 + g8;
+                    const int t = chunk_ * CW + h * 8 + g8;
                     if (t < ro) {
                         // every loaded piece is stored; the adders only read
                         // the column's own (padded) length
-                        Float* dp = wst_p + (h * 8 + g8) * SP + 2 * l8;
-                        unsigned short* di = wst_i + (h * 8 + g8) * SI + 2 * l8;
+                        Float* dp = base_p + (h * 8 + g8) * SP + 2 * l8;
+                        unsigned short* di = base_i + (h * 8 + g8) * SI + 2 * l8;
 #pragma unroll
                         for (int b = 0; b < NP; ++b) {
-                            if (b < npm) {
+                            if (b < npm_) {
                                 *reinterpret_cast<Float2*>(dp + b * 16) = regP[h][b];
                                 *reinterpret_cast<unsigned*>(di + b * 16) = regI[h][b];
                             }
@@ -2229,30 +2240,48 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 // compiler has to be kept from reordering across this point
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+            };
+            for (; chunk < nchunks; chunk += nwaves) {
+                if (overflow && chunk == nwaves)
+                    continue; // summed together with chunk 0 (wave 0)
+                stage(wst_p, wst_i, chunk, npm);
                 BXH_STAMP(12);
-                if (chunk + nwaves < nchunks) {
+                const bool dual = overflow && chunk == 0;
+                if (dual) {
+                    const int npx = chunk_pieces(cs_s, nwaves);
+                    issue(cs_s, ro, nwaves, npx);
+                    stage(xst_p, xst_i, nwaves, npx);
+                    if (2 * nwaves < nchunks) {
+                        npm = chunk_pieces(cs_s, 2 * nwaves);
+                        issue(cs_s, ro, 2 * nwaves, npm);
+                    }
+                } else if (chunk + nwaves < nchunks) {
                     npm = chunk_pieces(cs_s, chunk + nwaves);
                     issue(cs_s, ro, chunk + nwaves, npm);
                 }
                 BXH_STAMP(13);
 
-                if (lane < 2 * CW) {
-                    const int u = lane & (CW - 1);
-                    const bool is_pi = lane >= CW;
-                    const int t = chunk * CW + u;
-                    if (t < ro) {
+                {
+                    const int half = lane >> 5; // 1: the overflow chunk
+                    const int lane5 = lane & 31;
+                    const int u = lane5 & (CW - 1);
+                    const bool is_pi = lane5 >= CW;
+                    const int t = (half ? nwaves : chunk) * CW + u;
+                    if ((half == 0 || dual) && t < ro) {
+                        Float* const my_p = half ? xst_p : wst_p;
+                        unsigned short* const my_i = half ? xst_i : wst_i;
                         const int2 cs = cs_s[t];
                         const int cpad = cs.y & 0xffff;
                         if (!is_pi) { // P[e] *= theta for this row's entry
-                            Float* pk = wst_p + u * SP + (pe_s[t] - cs.x);
+                            Float* pk = my_p + u * SP + (pe_s[t] - cs.x);
                             const Float dec = *pk * theta; // (stored to HBM by affect)
                             *pk = dec;
                             pown_s[t] = dec;
                         }
                         const Float2* sp2 =
-                          reinterpret_cast<const Float2*>(wst_p + u * SP);
+                          reinterpret_cast<const Float2*>(my_p + u * SP);
                         const uint2* si2 =
-                          reinterpret_cast<const uint2*>(wst_i + u * SI);
+                          reinterpret_cast<const uint2*>(my_i + u * SI);
                         Float acc = 0;
                         for (int i0 = 0; i0 < cpad; i0 += 16) {
                             Float v[16];
@@ -2314,6 +2343,28 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // their values).
         const unsigned xoff = (unsigned)(it & 1) * (unsigned)pb.rmax * 16u;
         const unsigned tag32 = ((a.epoch & 0x1ffffu) << 15) | (unsigned)(it + 1);
+
+        // ---- the next row's descriptor -> LDS and the row constants, BEFORE
+        // this row's stores: their registers were loaded a row ago, so the
+        // wait for them returns at once here, while behind the write-through
+        // stores it would also wait for the stores' acknowledgements -----------
+        if (it + 1 < nrows)
+            store_desc(x1, cur ^ 1);
+        if (tid == 64 % T) { // row constants of select_variables, off thread 0
+            misc_s[MS_BMIN] = c_bmin;
+            misc_s[MS_BMAX] = c_bmax;
+            misc_s[MS_BNEG] = c_bneg;
+            *(double*)(misc_s + MS_RBYTES) = c_rbytes;
+            // slots of the selection's LDS-atomic reductions (part_s[64..])
+            part_s[64] = 0ull;  // largest key
+            part_s[65] = 0ull;  // largest N key
+            part_s[66] = ~0ull; // smallest S key
+            part_s[67] = 0ull;  // counts: N in the high half, Z in the low half
+            part_s[68] = 0ull;  // tie flag
+            part_s[69] = ~0ull; // smallest key
+        }
+        BXH_STAMP(11);
+
         for (int l = tid; l < ro; l += T) {
             const int idx = MW ? oidx_s[l] : l; // position in the whole row
             const int j = col_s[l];
@@ -2330,58 +2381,49 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 const v4u g = { (unsigned)bits, tag32, (unsigned)(bits >> 32), tag32 };
                 // both granules by one write-through (sc1) 16-byte store
                 __builtin_amdgcn_raw_buffer_store_b128(g, xrsrc, xoff + (unsigned)idx * 16u, 0, 16);
-            } else {
-                val_s[idx] = v;
             }
+            val_s[idx] = v; // own values do not travel
         }
-        // ---- the next row's descriptor -> LDS, the one after it -> registers
-        // (between the owners' stores and the polling of the partners' values:
-        // no younger loads are in flight here, so waiting for these registers
-        // waits for nothing else) -------------------------------------
-        if (it + 1 < nrows) {
-            store_desc(x1, cur ^ 1);
-            if (it + 2 < nrows) {
-                fetch_desc(x2);
-                if (it + 3 < nrows) {
-                    x3 = row_extent(k3);
-                    if (it + 4 < nrows)
-                        k4 = row_at(it + 4);
-                }
+        // the descriptor after the next -> registers, the next row constants
+        // (loads only: nothing here waits)
+        if (it + 2 < nrows) {
+            fetch_desc(x2);
+            if (it + 3 < nrows) {
+                x3 = row_extent(k3);
+                if (it + 4 < nrows)
+                    k4 = row_at(it + 4);
             }
-        }
-        BXH_STAMP(11);
-        if (tid == 64 % T) { // row constants of select_variables, off thread 0
-            misc_s[MS_BMIN] = c_bmin;
-            misc_s[MS_BMAX] = c_bmax;
-            misc_s[MS_BNEG] = c_bneg;
-            *(double*)(misc_s + MS_RBYTES) = c_rbytes;
-            // slots of the selection's LDS-atomic reductions (part_s[64..])
-            part_s[64] = 0ull;  // largest key
-            part_s[65] = 0ull;  // largest N key
-            part_s[66] = ~0ull; // smallest S key
-            part_s[67] = 0ull;  // counts: N in the high half, Z in the low half
-            part_s[68] = 0ull;  // tie flag
-            part_s[69] = ~0ull; // smallest key
         }
         if (it + 1 < nrows)
             fetch_consts(x1.k);
         BXH_STAMP(1);
         if (MW) {
-            for (int idx = tid; idx < r; idx += T) {
-                v4u g;
-                long spins = 0;
-                for (;;) { // L1-bypassing (sc1) 16-byte load of both granules
-                    g = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + (unsigned)idx * 16u, 0, 16);
-                    if (g.y == tag32 && g.w == tag32)
-                        break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > 2000000L) { // a partner is missing: give up loudly
-                        __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
+            // The waves that stored do not poll: a wave's loads would also
+            // wait for the acknowledgement of its own write-through stores
+            // (one counter).  The other waves fetch the partners' values.
+            const int nstore = min(T, ((ro + 63) >> 6) << 6);
+            const int npoll = T - nstore;
+            const int first = npoll >= 64 ? tid - nstore : tid;
+            const int step = npoll >= 64 ? npoll : T;
+            if (first >= 0) {
+                for (int idx = first; idx < r; idx += step) {
+                    if (loc_s[idx] >= 0)
+                        continue; // own
+                    v4u g;
+                    long spins = 0;
+                    for (;;) { // L1-bypassing (sc1) 16-byte load of both granules
+                        g = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + (unsigned)idx * 16u, 0, 16);
+                        if (g.y == tag32 && g.w == tag32)
+                            break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > 2000000L) { // a partner is missing: give up loudly
+                            __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
                     }
+                    const unsigned long long bits = (unsigned long long)g.x | ((unsigned long long)g.z << 32);
+                    val_s[idx] = (Float)__longlong_as_double((long long)bits);
                 }
-                const unsigned long long bits = (unsigned long long)g.x | ((unsigned long long)g.z << 32);
-                val_s[idx] = (Float)__longlong_as_double((long long)bits);
             }
         }
         const int n2 = next_pow2(r < 2 ? 2 : r);
