@@ -208,3 +208,105 @@ def test_quadratic_objective_lane_per_column_kernel(oracle, bxh, monkeypatch):
     for case in (Q_CASES[0], Q_CASES[3]):
         _, maker, float_type, maximize, order, x0p = case
         run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
+
+
+def _custom(rows, n, cmin, cmax, costs, factor=None, kind=1, maximize=False, name="edge"):
+    row_ptr = np.zeros(len(rows) + 1, np.int32)
+    for k, r in enumerate(rows):
+        row_ptr[k + 1] = row_ptr[k] + len(r)
+    col = np.concatenate([np.asarray(r, np.int32) for r in rows])
+    fac = np.ones(col.shape[0], np.int32) if factor is None else np.asarray(factor, np.int32)
+    return synth.Instance(m=len(rows), n=n, row_ptr=row_ptr, col=col, factor=fac,
+                          cmin=np.asarray(cmin, np.int32), cmax=np.asarray(cmax, np.int32),
+                          obj_var=np.arange(n, dtype=np.int32), obj_factor=np.asarray(costs, np.float64),
+                          maximize=maximize, kind=kind, name=name)
+
+
+def edge_ragged():
+    """Rows of 1, 2 and 3 elements next to a row over every variable; a
+    variable no row mentions; a variable in every row."""
+    rs = np.random.RandomState(70)
+    n = 90
+    rows = [[0], [0, 1], [0, 2, 3], list(range(0, 89)), [0, 5], [0] + list(range(10, 60)), [0, 7, 8, 9]]
+    for _ in range(25):
+        rows.append([0] + sorted(rs.choice(np.arange(1, 89), size=int(rs.randint(1, 12)), replace=False)))
+    m = len(rows)
+    return _custom(rows, n, [1] * m, [len(r) for r in rows], rs.randint(1, 30, size=n))
+
+
+def edge_long_rows():
+    """A row longer than twice the workgroup (the bitonic-sort path) and
+    equality rows with an interior right-hand side (interior ranks)."""
+    rs = np.random.RandomState(71)
+    n = 1300
+    rows = [list(range(n)), list(range(0, n, 2))]
+    cmin, cmax = [3, 5], [3, 5]
+    for _ in range(30):
+        size = int(rs.randint(20, 200))
+        rows.append(sorted(rs.choice(n, size=size, replace=False)))
+        b = int(rs.randint(1, 6))
+        cmin.append(b)
+        cmax.append(b + int(rs.randint(0, 3)))
+    return _custom(rows, n, cmin, cmax, 1 + 99 * rs.random_sample(n))
+
+
+def edge_long_columns():
+    """Columns with more than 128 entries (the staged kernel cannot take
+    them: lane-per-column kernel) -- 300 rows that all share 5 variables."""
+    rs = np.random.RandomState(72)
+    n = 400
+    rows = []
+    for _ in range(300):
+        rest = sorted(rs.choice(np.arange(5, n), size=int(rs.randint(3, 15)), replace=False))
+        rows.append([0, 1, 2, 3, 4] + rest)
+    m = len(rows)
+    return _custom(rows, n, [2] * m, [6] * m, rs.randint(1, 50, size=n))
+
+
+EDGE_CASES = [
+    ("ragged", edge_ragged, 1, False, 0, 0.0),
+    ("ragged-f32-rand", edge_ragged, 0, False, 2, 0.3),
+    ("long-rows", edge_long_rows, 1, False, 0, 0.0),
+    ("long-rows-max", edge_long_rows, 1, True, 1, 0.5),
+    ("long-columns", edge_long_columns, 1, False, 0, 0.1),
+]
+
+
+@pytest.mark.parametrize("groups", ["1", "4"])
+@pytest.mark.parametrize("case", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_edge_shapes_match_oracle(oracle, bxh, case, groups, monkeypatch):
+    """Ragged rows (down to one element), a variable in no row and one in every
+    row, rows longer than the workgroup, interior ranks, columns too long for
+    the staged kernel."""
+    monkeypatch.delenv("BXH_FORCE_V1", raising=False)
+    monkeypatch.setenv("BXH_GROUPS", groups)
+    _, maker, float_type, maximize, order, x0p = case
+    run_case(oracle, bxh, maker(), float_type, maximize, order, x0p, sweeps=8, push_at=(3, 6))
+
+
+def test_invalid_inputs_are_refused(bxh):
+    """bxh_create validates what the Solver constructors assume."""
+    inst = synth.make_scp(10, 30, 0.2, "int", 73)
+    bad = synth.make_scp(10, 30, 0.2, "int", 73)
+    bad.col = bad.col.copy()
+    bad.col[0] = 99  # column out of range
+    with pytest.raises(RuntimeError):
+        bxh.DeviceBatch(bad, bad.dense_costs(), 1)
+    bad = synth.make_scp(10, 30, 0.2, "int", 73)
+    bad.factor = bad.factor.copy()
+    bad.factor[0] = 3  # not a 0/1 coefficient for the 01 solver
+    with pytest.raises(RuntimeError):
+        bxh.DeviceBatch(bad, bad.dense_costs(), 1)
+    bad = synth.make_scp(10, 30, 0.2, "int", 73)
+    bad.cmin = bad.cmin.copy()
+    bad.cmin[0] = 1000  # min > max after clamping
+    bad.cmax = bad.cmax.copy()
+    bad.cmax[0] = 2
+    with pytest.raises(RuntimeError):
+        bxh.DeviceBatch(bad, bad.dense_costs(), 1)
+    dev = bxh.DeviceBatch(inst, inst.dense_costs(), 2)
+    with pytest.raises(RuntimeError):
+        dev.sweep(-0.5, 0.01, 0.5)  # negative kappa
+    with pytest.raises(RuntimeError):
+        dev.order_create(42)
+    dev.close()
