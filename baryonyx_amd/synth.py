@@ -296,6 +296,12 @@ def config_c1(cost_kind="int"):
     return make_scp(200, 1000, 0.02, cost_kind, seed=41)
 
 
+def config_c5(cost_kind="int"):
+    """telebus-shaped stand-in (general integer coefficients, inequalities-Z):
+    1000 knapsack rows over 5000 variables, ~50 elements per long row."""
+    return make_z(1000, 5000, 0.01, cost_kind, seed=5)
+
+
 def config_c2(cost_kind="int"):
     return make_scp(1000, 10000, 0.05, cost_kind, seed=1)
 

@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="restarts per GPU")
     ap.add_argument("--float", dest="float_kind", choices=["double", "float"], default="double")
     ap.add_argument("--cost-kind", choices=["int", "real"], default="int")
-    ap.add_argument("--config", choices=["c1", "c2", "c3"], default="c2")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c5"], default="c2")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="wall budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
@@ -59,7 +59,8 @@ def parse():
 def make_instance(args):
     from baryonyx_amd import synth
 
-    return {"c1": synth.config_c1, "c2": synth.config_c2, "c3": synth.config_c3}[args.config](
+    return {"c1": synth.config_c1, "c2": synth.config_c2, "c3": synth.config_c3,
+            "c5": synth.config_c5}[args.config](
         args.cost_kind
     )
 
@@ -85,9 +86,11 @@ def cpu_run(inst, params, float_type, seconds, nthreads):
     stop_at = [0.0]
 
     def work(t):
+        from baryonyx_amd.util import pack_bits
         s = O.Solver(inst, float_type=float_type, sort_mode=1, cost_norm=4, seed=1000 + t)
         delta = s.compute_delta(params.theta)
-        x0 = np.zeros(s.nwords, np.uint64)
+        bast = (inst.dense_costs() > 0) if inst.maximize else (inst.dense_costs() < 0)
+        x0 = pack_bits(bast.astype(np.uint8))
         k = 0
         while time.perf_counter() < stop_at[0]:
             s.set_x(x0)
@@ -184,7 +187,12 @@ def main():
     for b in range(args.batch):  # one std engine per worker, distinct seeds
         dev.set_rng(b, 1 + ((1 + rank) * 7919 + b * 104729) % 2147483645)
     scan_bytes = inst.nnz * 4 + inst.nnz / 8  # violated-row scan, per instance and sweep
-    x0 = np.zeros((args.batch, dev.nwords), np.uint64)  # Bastert point of a min-cost SCP
+    # the Bastert point (init_with_bastert, itm-common.hpp:255-283): x_j = 1 where
+    # the cost pulls that way -- all zeros for a min-cost covering instance
+    from baryonyx_amd.util import pack_bits
+    bast = (inst.dense_costs() > 0) if inst.maximize else (inst.dense_costs() < 0)
+    x0 = np.tile(pack_bits(bast.astype(np.uint8)), (args.batch, 1))
+    assert x0.shape[1] == dev.nwords
 
     def barrier():
         if world > 1:
@@ -243,8 +251,12 @@ def main():
         per_launch_bytes = alg / max(launches, 1)
         per_launch_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-        workload = (f"{inst.name}: scpnrh1-shaped SCP {inst.m}x{inst.n} nnz={inst.nnz}, "
-                    f"inequalities-01, {args.batch} restarts/GPU, {args.cost_kind} costs")
+        shape = {"c1": "scp41-shaped SCP", "c2": "scpnrh1-shaped SCP", "c3": "aa04-shaped SPP",
+                 "c5": "telebus-shaped knapsack rows"}[args.config]
+        solver = ["equalities-01", "inequalities-01", "equalities-101", "inequalities-101",
+                  "inequalities-Z"][inst.kind]
+        workload = (f"{inst.name}: {shape} {inst.m}x{inst.n} nnz={inst.nnz}, "
+                    f"{solver}, {args.batch} restarts/GPU, {args.cost_kind} costs")
         out = {
             "metric": "row-updates/sec (itm inner loop)",
             "value": rows_all / dt_max,
