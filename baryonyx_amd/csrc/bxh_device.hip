@@ -1240,6 +1240,17 @@ bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* r
                                hipMemcpyHostToDevice, h->stream));
         dev_active = h->active.p;
     }
+    // the row scan on several workgroups per instance when the batch alone
+    // does not fill the device, then the ordered compaction per instance
+    int parts = 1;
+    while (parts < 8 && h->batch * parts * 2 <= 512 && h->m / (parts * 2) >= 64)
+        parts *= 2;
+    if (parts > 1) {
+        hipLaunchKernelGGL(bxh::order_flags_kernel, dim3(h->batch * parts), dim3(1024),
+                           static_cast<size_t>(h->nwords) * 8, h->stream, h->dp, h->ds,
+                           h->order_b.p, dev_active, parts);
+        HIP_TRY(hipGetLastError());
+    }
     if (h->float_type == BXH_FLOAT)
         hipLaunchKernelGGL((bxh::order_init_kernel<float>),
                            dim3(h->batch),
@@ -1249,7 +1260,8 @@ bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* r
                            h->dp,
                            h->ds,
                            h->order_b.p,
-                           dev_active);
+                           dev_active,
+                           parts > 1 ? 1 : 0);
     else
         hipLaunchKernelGGL((bxh::order_init_kernel<double>),
                            dim3(h->batch),
@@ -1259,7 +1271,8 @@ bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* r
                            h->dp,
                            h->ds,
                            h->order_b.p,
-                           dev_active);
+                           dev_active,
+                           parts > 1 ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (remaining) {
         HIP_TRY(hipStreamSynchronize(h->stream));

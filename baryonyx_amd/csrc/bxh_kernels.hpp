@@ -646,18 +646,14 @@ wave_sum(int v)
 
 // compute_violated_constraints (itm-common.hpp:102-115): rebuild the ordered
 // list of rows whose activity is outside [bmin, bmax].  x is read from LDS.
+// First the flags of rows [k0, k1) (wave per row), then the ordered compaction.
 __device__ inline int
-rebuild_violated(const DevProblem& pb,
-                 const unsigned* x_s,
-                 signed char* vflag,
-                 int* vlist,
-                 int* scratch_s /* >= 64 ints */)
+flag_violated(const DevProblem& pb, const unsigned* x_s, signed char* vflag, int k0, int k1)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
     const bool pm1 = pb.kind == 2 || pb.kind == 3;
-
-    for (int k = wave; k < pb.m; k += nwaves) {
+    for (int k = k0 + wave; k < k1; k += nwaves) {
         const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
         int v = 0;
         for (int e = rs + lane; e < re; e += 64) {
@@ -669,6 +665,22 @@ rebuild_violated(const DevProblem& pb,
         if (lane == 0)
             vflag[k] = !(pb.bmin[k] <= v && v <= pb.bmax[k]);
     }
+    return 0;
+}
+
+__device__ inline int
+rebuild_violated(const DevProblem& pb,
+                 const unsigned* x_s,
+                 signed char* vflag,
+                 int* vlist,
+                 int* scratch_s /* >= 64 ints */,
+                 bool flags_ready = false)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+
+    if (!flags_ready)
+        flag_violated(pb, x_s, vflag, 0, pb.m);
     __syncthreads(); // vflag is only read back by this workgroup (same CU)
 
     int base = 0;
@@ -825,9 +837,34 @@ rebuild_infeasibility(const DevProblem& pb,
 
 // compute_order::init (itm-common.hpp:660-680) of the instances `active`
 // selects (all when null), by each instance's current order.
+// First half of compute_violated_constraints on `parts` workgroups per
+// instance (blockIdx = inst * parts + part): which rows are violated.
+__global__ __launch_bounds__(1024) void
+order_flags_kernel(DevProblem pb, DevState st, const int* order_b, const unsigned char* active,
+                   int parts)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned* x_s = (unsigned*)smem;
+    const int inst = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int tid = threadIdx.x, T = blockDim.x;
+    if (active && !active[inst])
+        return;
+    const int ord = order_b ? order_b[inst] : 0;
+    if (ord == 3 || ord == 4)
+        return; // the infeasibility orders compute amounts, in order_init_kernel
+    const unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        x_s[i] = xg[i];
+    __syncthreads();
+    const int per = (pb.m + parts - 1) / parts;
+    const int k0 = part * per, k1 = min(pb.m, k0 + per);
+    flag_violated(pb, x_s, st.vflag + (size_t)inst * pb.m, k0, k1);
+}
+
 template<typename Float>
 __global__ __launch_bounds__(1024) void
-order_init_kernel(DevProblem pb, DevState st, const int* order_b, const unsigned char* active)
+order_init_kernel(DevProblem pb, DevState st, const int* order_b, const unsigned char* active,
+                  int flags_ready)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LdsPlan lp = lds_plan(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float));
@@ -865,7 +902,8 @@ order_init_kernel(DevProblem pb, DevState st, const int* order_b, const unsigned
                                          x_s,
                                          st.vflag + (size_t)inst * pb.m,
                                          st.slist + (size_t)inst * st.lcap,
-                                         misc_s + MS_WAVES);
+                                         misc_s + MS_WAVES,
+                                         flags_ready != 0);
         if (tid == 0) {
             st.vcount[inst] = pb.n;
             st.status[inst].remaining = cnt;
@@ -873,7 +911,7 @@ order_init_kernel(DevProblem pb, DevState st, const int* order_b, const unsigned
         return;
     }
     const int cnt = rebuild_violated(
-      pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES);
+      pb, x_s, st.vflag + (size_t)inst * pb.m, vlist, misc_s + MS_WAVES, flags_ready != 0);
     if (tid == 0) {
         st.vcount[inst] = cnt;
         st.status[inst].remaining = cnt;
