@@ -1370,7 +1370,12 @@ __host__ __device__ inline int
 lds_bytes_z(int m, int nwords, int rmax, int fsize)
 {
     const LdsPlan lp = lds_plan(m, nwords, rmax, fsize);
-    return lp.total + 2 * (((rmax + 1) * 4 + 15) & ~15);
+    const int n2 = next_pow2(rmax < 64 ? 64 : rmax); // whole 64-entry runs
+    // + factor and 0/1 result per R position, + the sorted runs of
+    // run_merge_sort, + the row's descriptors {first slot, padded length,
+    // own slot, column} by row-local id
+    return lp.total + 2 * (((rmax + 1) * 4 + 15) & ~15) + ((n2 * 8 + 15) & ~15) +
+           ((n2 * 4 + 15) & ~15) + ((rmax * 16 + 15) & ~15);
 }
 
 // Node stack of branch_and_bound_solver (branch-and-bound-solver.hpp:195-536)
@@ -1538,6 +1543,11 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     Float* d_s = (Float*)(misc_s + MS_D);
     int* fz_s = (int*)(smem + lp.total);                                   // R[i].f
     int* res_s = (int*)(smem + lp.total + (((pb.rmax + 1) * 4 + 15) & ~15)); // 0/1 per position
+    const int n2max = next_pow2(pb.rmax < 64 ? 64 : pb.rmax); // whole 64-entry runs
+    unsigned long long* key_run =
+      (unsigned long long*)(smem + lp.total + 2 * (((pb.rmax + 1) * 4 + 15) & ~15));
+    int* id_run = (int*)((unsigned char*)key_run + ((n2max * 8 + 15) & ~15));
+    int4* desc_s = (int4*)((unsigned char*)id_run + ((n2max * 4 + 15) & ~15)); // by row-local id
 
     const int tid = threadIdx.x, T = blockDim.x;
     const bool maximize = pb.maximize != 0;
@@ -1583,30 +1593,71 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     // c_j - sum over column j of |a| * (pi + P), one accumulator, CSC order
     // (local_compute_reduced_cost, :295-306); `pe` / `pown` substitute the
     // row's own entry (not yet in HBM)
-    auto column_rc = [&](int j, int pe, Float pown) -> Float {
+    // (columns are stored padded to 16 slots with P = 0 and |a| = 0: eight
+    // entries are loaded at a time, all loads in flight together, and a
+    // padding term 0 * (pi + 0) leaves the running sum bit-identical)
+    auto column_rc = [&](int j, int q0, int padlen, int pe, Float pown) -> Float {
         Float acc = 0;
-        const int q0 = pb.col_start[j];
-        const int qe = q0 + pb.col_len[j];
-        for (int q = q0; q < qe; ++q) {
-            const Float p = q == pe ? pown : P[q];
-            const Float fa = (Float)pb.col_fac[q];
-            acc += fa * (pi_s[pb.col_row[q]] + p);
+        const int qe = q0 + padlen;
+        for (int qb = q0; qb < qe; qb += 8) {
+            Float p8[8];
+            int f8[8], r8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                p8[u] = P[qb + u];
+                f8[u] = pb.col_fac[qb + u];
+                r8[u] = pb.col_row[qb + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const Float p = qb + u == pe ? pown : p8[u];
+                const int ri = r8[u] < pb.m ? r8[u] : 0; // padding: any finite pi
+                acc += (Float)f8[u] * (pi_s[ri] + p);
+            }
         }
         return cost_x<Float>(pb, x_s, j, cost[j]) - acc;
     };
 
+    // the next row's scalars travel while this row is worked on
+    struct RowZ
+    {
+        int k, rs, re, zk, bmin, bmax;
+        double rbytes;
+    };
+    auto row_of = [&](int it_) -> RowZ {
+        RowZ x;
+        x.k = (ord == 1) ? vlist[nrows - 1 - it_] : vlist[it_];
+        x.rs = pb.row_ptr[x.k];
+        x.re = pb.row_ptr[x.k + 1];
+        x.zk = pb.zkind[x.k];
+        x.bmin = pb.bmin[x.k];
+        x.bmax = pb.bmax[x.k];
+        x.rbytes = pb.row_bytes[x.k];
+        return x;
+    };
+    RowZ nxt = { 0, 0, 0, 0, 0, 0, 0.0 };
+    if (nrows > 0)
+        nxt = row_of(0);
     for (int it = 0; it < nrows; ++it) {
-        const int k = (ord == 1) ? vlist[nrows - 1 - it] : vlist[it];
-        const int rs = pb.row_ptr[k];
-        const int r = pb.row_ptr[k + 1] - rs;
-        const int zk = pb.zkind[k];
+        const RowZ cur = nxt;
+        if (it + 1 < nrows)
+            nxt = row_of(it + 1);
+        const int k = cur.k;
+        const int rs = cur.rs;
+        const int r = cur.re - cur.rs;
+        const int zk = cur.zk;
 
         // ---- decrease_preference + compute_reduced_costs (+ push) ----------
         for (int idx = tid; idx < r; idx += T) {
+            // three independent loads from e (no chase through the column id)
             const int e = rs + idx;
+            const int2 cs = pb.row_cs[e];
             const int j = pb.row_col[e];
             const int pe = pb.row_pos[e];
-            Float v = column_rc(j, pe, P[pe] * theta);
+            const int padlen = cs.y & 0xffff;
+            desc_s[idx] = make_int4(cs.x, padlen, pe, j);
+            res_s[idx] = pb.fac32[e]; // factor by row-local id (res_s is free until the sub-solvers)
+            Float v = column_rc(j, cs.x, padlen, pe, P[pe] * theta);
             if (push) // :467-469: the true column
                 v += obj_amp * cost_x<Float>(pb, x_s, j, cost[j]);
             val_s[idx] = v;
@@ -1618,13 +1669,20 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
 
         // ---- calculator_sort (every kind but the plain exhaustive one) -----
         if (zk != Z_EXHAUSTIVE) {
-            for (int i = tid; i < n2; i += T) {
-                key_s[i] = i < r ? order_key<Float>(val_s[i], maximize) : ~0ull;
-                id_s[i] = i;
+            if (r > 1 && r <= 2 * T && r <= 1024) {
+                // wave-sorted runs + rank search: 2 barriers instead of ~25
+                Prof noprof;
+                noprof.t = 0;
+                run_merge_sort<Float>(val_s, r, maximize, key_run, id_run, key_s, id_s, &noprof);
+            } else {
+                for (int i = tid; i < n2; i += T) {
+                    key_s[i] = i < r ? order_key<Float>(val_s[i], maximize) : ~0ull;
+                    id_s[i] = i;
+                }
+                __syncthreads();
+                if (r > 1)
+                    bitonic_sort(key_s, id_s, n2);
             }
-            __syncthreads();
-            if (r > 1)
-                bitonic_sort(key_s, id_s, n2);
             for (int i = tid; i + 1 < r; i += T)
                 if (key_s[i] == key_s[i + 1])
                     misc_s[MS_TIE] = 1;
@@ -1644,15 +1702,75 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         }
         __syncthreads();
         for (int i = tid; i < r; i += T)
-            fz_s[i] = pb.fac32[rs + id_s[i]];
+            fz_s[i] = res_s[id_s[i]];
         __syncthreads();
 
         // ---- selection ------------------------------------------------------
-        const int bkmin = pb.bmin[k], bkmax = pb.bmax[k];
+        const int bkmin = cur.bmin, bkmax = cur.bmax;
+        // select_variables (:308-344) on all lanes when the row fits the
+        // workgroup: with S_i the running sum of the factors of R[0..i]
+        // (S_-1 = 0), the scan keeps the last i whose S_i is within the bounds
+        // and leaves at the first i, at or after the first such one, whose
+        // successor R[i + 1] has a stopping value (R[r] as the reference's
+        // array still holds it).
+        const bool par_select = r <= T && (zk == Z_LINEAR || zk == Z_UNCONSTRAINED_BB ||
+                                           zk == Z_UNCONSTRAINED_EXHAUSTIVE);
+        if (par_select) {
+            const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+            int* wsum = misc_s + MS_WAVES; // per-wave totals, then the three results
+            const int f = tid < r ? fz_s[tid] : 0;
+            int incl = f; // inclusive scan inside the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off)
+                    incl += o;
+            }
+            if (lane == 63)
+                wsum[wave] = incl;
+            if (tid == 0) {
+                wsum[32] = 0x7fffffff; // first valid i
+                wsum[33] = 0x7fffffff; // leaving i
+                wsum[34] = -2;         // best
+            }
+            __syncthreads();
+            int S = incl;
+            for (int w = 0; w < wave; ++w)
+                S += wsum[w];
+            auto stops = [&](Float v) -> bool { return maximize ? v < 0 : v > 0; };
+            const bool in_row = tid < r;
+            const bool valid = in_row && bkmin <= S && S <= bkmax;          // i = tid
+            const bool valid_m1 = bkmin <= 0 && 0 <= bkmax;                 // i = -1
+            const Float next_v = tid + 1 < r ? val_s[id_s[tid + 1]] : stale_s[tid + 1 <= pb.rmax ? tid + 1 : pb.rmax];
+            const bool stop_i = in_row && stops(next_v);                    // R[i + 1]
+            const bool stop_m1 = stops(r > 0 ? val_s[id_s[0]] : stale_s[0]);
+            if (valid)
+                atomicMin(&wsum[32], tid);
+            if (tid == 0 && valid_m1)
+                atomicMin(&wsum[32], -1);
+            __syncthreads();
+            const int first_valid = wsum[32];
+            if (first_valid != 0x7fffffff) {
+                if (stop_i && tid >= first_valid)
+                    atomicMin(&wsum[33], tid);
+                if (tid == 0 && stop_m1 && -1 >= first_valid)
+                    atomicMin(&wsum[33], -1);
+            }
+            __syncthreads();
+            const int leave = wsum[33] == 0x7fffffff ? r - 1 : wsum[33];
+            if (first_valid != 0x7fffffff) {
+                if (valid && tid <= leave)
+                    atomicMax(&wsum[34], tid);
+                if (tid == 0 && valid_m1 && -1 <= leave)
+                    atomicMax(&wsum[34], -1);
+            }
+            __syncthreads();
+        }
         if (tid == 0) {
-            alg_bytes += pb.row_bytes[k];
+            alg_bytes += cur.rbytes;
             int sel = -2;
-            if (zk == Z_LINEAR || zk == Z_UNCONSTRAINED_BB || zk == Z_UNCONSTRAINED_EXHAUSTIVE) {
+            if (r > T && (zk == Z_LINEAR || zk == Z_UNCONSTRAINED_BB ||
+                          zk == Z_UNCONSTRAINED_EXHAUSTIVE)) {
                 // select_variables, :308-344 (reads R[i + 1] up to R[r])
                 auto Rv = [&](int i) -> Float { return i < r ? val_s[id_s[i]] : stale_s[i]; };
                 int sum = 0;
@@ -1670,6 +1788,8 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                     // (i + 1 == r: the reference adds the stale R[r].f and leaves)
                 }
             }
+            if (par_select)
+                sel = (misc_s + MS_WAVES)[34];
             misc_s[MS_SEL] = sel;
             misc_s[MS_SELMODE] = 0; // 1: B&B wanted, 2: exhaustive wanted
             if (zk == Z_BB || (zk == Z_UNCONSTRAINED_BB && sel == -2))
@@ -1793,21 +1913,21 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
             const bool serial = pb.q_ptr != nullptr;
             for (int i = serial ? 0 : tid; i < (serial && tid != 0 ? 0 : r); i += serial ? 1 : T) {
                 const int idx = id_s[i];
-                const int e = rs + idx;
-                const int j = pb.row_col[e];
-                const int pe = pb.row_pos[e];
+                const int4 dd = desc_s[idx];
+                const int j = dd.w;
+                const int pe = dd.z;
                 const bool up = sel < 0 ? false : (sel + 1 >= r ? true : i <= sel);
                 Float p = P[pe] * theta;
                 if (up) {
                     atomicOr(&x_s[j >> 5], 1u << (j & 31));
                     p = p + d;
-                    const Float repair = column_rc(j, pe, p);
+                    const Float repair = column_rc(j, dd.x, dd.y, pe, p);
                     if (repair >= 0)
                         p = p - repair + d;
                 } else {
                     atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
                     p = p - d;
-                    const Float repair = column_rc(j, pe, p);
+                    const Float repair = column_rc(j, dd.x, dd.y, pe, p);
                     if (repair <= 0)
                         p = p + repair - d;
                 }
@@ -1899,7 +2019,7 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
     const int stage_p = al(slots * (np * 16 + 2) * fsize);
     const int stage = stage_p + al(slots * (np * 16 + 4) * 2);
     p.stage_i_off = stage_p;
-    const int n2 = next_pow2(rmax < 2 ? 2 : rmax);
+    const int n2 = next_pow2(rmax < 64 ? 64 : rmax); // whole 64-entry runs
     const int sortb = 2 * (al(n2 * 8) + al(n2 * 4)); // runs + merged output
     o = al(o + (stage > sortb ? stage : sortb));
     p.total = o;
@@ -1961,7 +2081,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     // union: staging during the reduced-cost passes, sort buffers afterwards
     Float* stg_p = (Float*)(smem + lp.off_union);
     unsigned short* stg_i = (unsigned short*)(smem + lp.off_union + lp.stage_i_off);
-    const int n2max = next_pow2(pb.rmax < 2 ? 2 : pb.rmax);
+    const int n2max = next_pow2(pb.rmax < 64 ? 64 : pb.rmax); // whole 64-entry runs
     unsigned long long* key_s = (unsigned long long*)(smem + lp.off_union);
     int* id_s = (int*)(smem + lp.off_union + ((n2max * 8 + 15) & ~15));
     // tie-detection table of the sort-free path: 2 * n2max 64-bit slots, over
