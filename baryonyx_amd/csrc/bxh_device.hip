@@ -119,6 +119,7 @@ struct bxh_handle_s
     // inequalities-Z
     DevBuf<int> fac32, col_fac, ex_start, ex_count, ex_flat;
     DevBuf<int> q_ptr, q_id;            // quadratic objective
+    DevBuf<unsigned> lcg_pow;           // 16807^k mod 2^31-1
     DevBuf<unsigned char> q_factor;
     DevBuf<signed char> zkind;
     DevBuf<unsigned char> zscratch;
@@ -776,6 +777,15 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->bmax.upload(bmax));
     HIP_TRY(h->bneg.upload(bneg));
     HIP_TRY(h->fac_csr.upload(fac_csr));
+    {
+        std::vector<unsigned> pw(1026);
+        unsigned long long v = 1;
+        for (size_t k = 0; k != pw.size(); ++k) {
+            pw[k] = static_cast<unsigned>(v);
+            v = v * 16807ull % 2147483647ull;
+        }
+        HIP_TRY(h->lcg_pow.upload(pw));
+    }
     if (pb->n_quad > 0) {
         HIP_TRY(h->q_ptr.upload(std::vector<int>(pb->q_ptr, pb->q_ptr + n + 1)));
         HIP_TRY(h->q_id.upload(std::vector<int>(pb->q_id, pb->q_id + pb->n_quad)));
@@ -1001,6 +1011,7 @@ bxh_create(const bxh_problem* pb,
     dp.q_id = h->q_id.p;
     dp.q_factor = h->q_factor.p;
     dp.row_bytes = h->row_bytes.p;
+    dp.lcg_pow = h->lcg_pow.p;
 
     bxh::DevState& ds = h->ds;
     ds.P = h->P.p;

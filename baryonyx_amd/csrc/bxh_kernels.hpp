@@ -68,6 +68,7 @@ struct DevProblem
     const int* q_id;           // [n_quad]
     const void* q_factor;      // [n_quad] Float
     const double* row_bytes;   // [m] algorithmic bytes of one update of row k
+    const unsigned* lcg_pow;   // [1026] 16807^k mod (2^31 - 1): jumps of minstd_rand0
 };
 
 struct DevStatus // == bxh_status
@@ -705,6 +706,183 @@ rebuild_violated(const DevProblem& pb,
         __syncthreads();
     }
     return base;
+}
+
+// ---------------------------------------------------------------------------
+// random_shuffle_unique (itm-common.hpp:117-131) for a whole workgroup: after
+// the sort every run of equal keys is shuffled with std::shuffle and the
+// row's engine.  The engine is a linear congruential one, so draw number g is
+// lcg_pow[g] * state (mod 2^31 - 1) and every position of every run can work out
+// its own swap partner at once (libstdc++'s pairwise scheme: one draw decides
+// two swaps, uniform_int_distribution's downscaling).  The Fisher-Yates swaps
+// of a run are then applied by tracing, for every final position, where its
+// element came from (backwards through the run's swaps).  A rejected draw
+// (probability below 1e-4 per draw) shifts every later draw: the function then
+// returns false, has changed nothing, and the caller takes the serial path.
+// Needs r <= 2 * blockDim.x <= 1024.  ids are permuted in place; *state is
+// advanced by the number of draws.  Scratch: three int arrays of r entries.
+__device__ inline unsigned
+lcg_jump(const unsigned* lcg_pow, unsigned state, int draws)
+{
+    unsigned long long x = (unsigned long long)lcg_pow[draws] * state; // < 2^62
+    x = (x & 0x7fffffffull) + (x >> 31);
+    x = (x & 0x7fffffffull) + (x >> 31);
+    return (unsigned)(x >= 0x7fffffffull ? x - 0x7fffffffull : x);
+}
+
+__device__ inline bool
+parallel_tie_shuffle(const unsigned long long* key_s,
+                     int* id_s,
+                     int r,
+                     unsigned* state, // in / out (uniform)
+                     const unsigned* lcg_pow,
+                     int* start_s,
+                     int* jt_s,
+                     int* tmp_s,
+                     int* scratch_s /* >= 40 ints */)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    const int p0 = 2 * tid, p1 = 2 * tid + 1;
+    const bool in0 = p0 < r, in1 = p1 < r;
+
+    // ---- run starts: inclusive max-scan of the head positions --------------
+    const bool h0 = in0 && (p0 == 0 || key_s[p0] != key_s[p0 - 1]);
+    const bool h1 = in1 && key_s[p1] != key_s[p0];
+    int m0 = h0 ? p0 : -1;
+    int m1 = h1 ? p1 : m0;
+    int agg = m1; // of the pair
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(agg, off, 64);
+        if (lane >= off)
+            agg = max(agg, o);
+    }
+    if (lane == 63)
+        scratch_s[wave] = agg;
+    if (tid == 0)
+        scratch_s[32] = 0; // rejection flag
+    __syncthreads();
+    int before = -1; // max over the earlier threads
+    {
+        const int up = __shfl_up(agg, 1, 64);
+        if (lane > 0)
+            before = up;
+        for (int w = 0; w < wave; ++w)
+            before = max(before, scratch_s[w]);
+    }
+    const int s0 = max(m0, before), s1 = max(m1, before);
+    if (in0)
+        start_s[p0] = s0;
+    if (in1)
+        start_s[p1] = s1;
+    // the last element of a run publishes its length at the run's start
+    const bool l0 = in0 && (p0 + 1 == r || (in1 ? h1 : true));
+    if (l0)
+        tmp_s[s0] = p0 - s0 + 1;
+    __syncthreads();
+    const bool l1 = in1 && (p1 + 1 == r || key_s[p1 + 1] != key_s[p1]);
+    if (l1)
+        tmp_s[s1] = p1 - s1 + 1;
+    __syncthreads();
+    const int L0 = in0 ? tmp_s[s0] : 1, L1 = in1 ? tmp_s[s1] : 1;
+
+    // ---- draw numbers: exclusive prefix sum of floor(L / 2) over the runs ---
+    const int d0 = (h0 ? (L0 >> 1) : 0), d1 = (h1 ? (L1 >> 1) : 0);
+    int sum = d0 + d1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(sum, off, 64);
+        if (lane >= off)
+            sum += o;
+    }
+    __syncthreads(); // scratch_s[0 .. nw) is reused
+    if (lane == 63)
+        scratch_s[wave] = sum;
+    __syncthreads();
+    int excl = sum - (d0 + d1);
+    int total = 0;
+    for (int w = 0; w < nw; ++w) {
+        if (w < wave)
+            excl += scratch_s[w];
+        total += scratch_s[w];
+    }
+    // draws before the run of p0 / p1: a head carries its own run's base
+    const int base0 = excl, base1 = excl + d0;
+    if (h0)
+        jt_s[p0] = base0; // base of the run, read through start_s below
+    if (h1)
+        jt_s[p1] = base1;
+    __syncthreads();
+    const int rb0 = in0 ? jt_s[s0] : 0, rb1 = in1 ? jt_s[s1] : 0;
+    __syncthreads();
+
+    // ---- the swap partner of every position i >= 1 of a run -----------------
+    const unsigned st0 = *state;
+    bool reject = false;
+    auto partner = [&](int p, int sp, int L, int rbase) -> int {
+        const int i = p - sp;
+        if (L < 2 || i == 0)
+            return 0;
+        const bool even = (L & 1) == 0;
+        unsigned urange; // the draw is uniform over [0, urange]
+        int d, half;
+        unsigned b1 = 2;
+        if (even && i == 1) {
+            d = 0;
+            half = 0;
+            urange = 1u;
+            b1 = 2u; // result / 1 ... handled below
+        } else {
+            const int i0 = even ? (i & ~1) : (((i - 1) & ~1) + 1); // first index of the pair
+            d = even ? (i >> 1) : ((i - 1) >> 1);
+            half = i - i0;
+            b1 = (unsigned)i0 + 2u;
+            urange = ((unsigned)i0 + 1u) * b1 - 1u;
+        }
+        const unsigned urngrange = 2147483645u;
+        const unsigned uerange = urange + 1u;
+        const unsigned scaling = urngrange / uerange;
+        const unsigned past = uerange * scaling;
+        const unsigned raw = lcg_jump(lcg_pow, st0, rbase + d + 1) - 1u;
+        if (raw >= past)
+            reject = true;
+        const unsigned x = raw / scaling;
+        if (even && i == 1)
+            return (int)x; // uniform(1)
+        return half == 0 ? (int)(x / b1) : (int)(x % b1);
+    };
+    const int j0 = in0 ? partner(p0, s0, L0, rb0) : 0;
+    const int j1 = in1 ? partner(p1, s1, L1, rb1) : 0;
+    if (reject)
+        scratch_s[32] = 1;
+    if (in0)
+        jt_s[p0] = j0;
+    if (in1)
+        jt_s[p1] = j1;
+    __syncthreads();
+    if (scratch_s[32])
+        return false;
+
+    // ---- where the element of every final position came from ----------------
+    auto origin = [&](int p, int sp, int L) -> int {
+        int pos = p - sp;
+        for (int i = L - 1; i >= 1; --i) {
+            const int j = jt_s[sp + i];
+            pos = pos == i ? j : (pos == j ? i : pos);
+        }
+        return sp + pos;
+    };
+    const int o0 = in0 ? id_s[origin(p0, s0, L0)] : 0;
+    const int o1 = in1 ? id_s[origin(p1, s1, L1)] : 0;
+    __syncthreads();
+    if (in0)
+        id_s[p0] = o0;
+    if (in1)
+        id_s[p1] = o1;
+    *state = lcg_jump(lcg_pow, st0, total);
+    __syncthreads();
+    return true;
 }
 
 // LDS carve shared by the kernels (host computes the same sizes).
@@ -1687,7 +1865,18 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 if (key_s[i] == key_s[i + 1])
                     misc_s[MS_TIE] = 1;
             __syncthreads();
-            if (tid == 0 && misc_s[MS_TIE]) {
+            bool shuffled = false;
+            if (misc_s[MS_TIE] && r > 1 && r <= 2 * T && r <= 1024) {
+                if (tid == 0) // the engine lives in thread 0 in this kernel
+                    misc_s[MS_RNG] = (int)rng.s;
+                __syncthreads();
+                unsigned stt = (unsigned)misc_s[MS_RNG];
+                shuffled = parallel_tie_shuffle(key_s, id_s, r, &stt, pb.lcg_pow, (int*)key_run,
+                                                (int*)key_run + n2max, id_run, misc_s + MS_WAVES);
+                if (shuffled)
+                    rng.s = stt;
+            }
+            if (tid == 0 && misc_s[MS_TIE] && !shuffled) {
                 int b0 = 0;
                 for (int i = 1; i <= r; ++i) {
                     if (i == r || key_s[i] != key_s[b0]) {
@@ -2897,11 +3086,21 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 misc_s[MS_TIE] = 1;
         __syncthreads();
         BXH_STAMP(4);
+        // the shuffle of the tied runs on all lanes (the buffers of the sorted
+        // runs are free again); a rejected draw leaves it to thread 0 below
+        bool shuffled = false;
+        if (misc_s[MS_TIE] && r <= 2 * T && r <= 1024) {
+            unsigned stt = rng.s;
+            shuffled = parallel_tie_shuffle(key_s, id_s, r, &stt, pb.lcg_pow, (int*)key_run,
+                                            (int*)key_run + n2max, id_run, misc_s + MS_WAVES);
+            if (shuffled)
+                rng.s = stt;
+        }
 
         // ---- thread 0: tie shuffle, select_variables, pi and d of affect ---
         if (tid == 0) {
             alg_bytes += *(const double*)(misc_s + MS_RBYTES);
-            if (misc_s[MS_TIE]) {
+            if (misc_s[MS_TIE] && !shuffled) {
                 int b0 = 0;
                 for (int i = 1; i <= r; ++i) {
                     if (i == r || key_s[i] != key_s[b0]) {
