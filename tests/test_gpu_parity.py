@@ -310,3 +310,35 @@ def test_invalid_inputs_are_refused(bxh):
     with pytest.raises(RuntimeError):
         dev.order_create(42)
     dev.close()
+
+
+def test_rejected_draw_in_a_tie_shuffle(oracle, bxh):
+    """uniform_int_distribution rejects a raw draw now and then; every later
+    draw of the row then shifts.  Engine state 898 meets a rejection while
+    shuffling a run of 300 equal reduced costs (the all-lanes shuffle gives up
+    and thread 0 redoes it), 899 does not."""
+    rs = np.random.RandomState(80)
+    n = 300
+    rows = [list(range(n))] + [sorted(rs.choice(n, size=40, replace=False)) for _ in range(20)]
+    m = len(rows)
+    inst = _custom(rows, n, [1] * m, [len(r) for r in rows], np.full(n, 7.0))
+    for seed in (898, 899):
+        s = oracle.Solver(inst, float_type=1, sort_mode=1, cost_norm=4, seed=1)
+        dev = bxh.DeviceBatch(inst, s.cost(), 1)
+        x0 = np.zeros(s.nwords, np.uint64)
+        s.set_x(x0)
+        dev.set_x(0, x0)
+        s.rng = seed
+        dev.set_rng(0, seed)
+        s.order_init(0)
+        dev.order_init(0)
+        d = s.compute_delta(0.5)
+        for it in range(3):
+            st = dev.sweep(0.1, d, 0.5)
+            rem = s.sweep(0.1, d, 0.5)
+            assert st["remaining"][0] == rem
+            assert st["rng"][0] == s.rng
+            assert np.array_equal(dev.get_x(0), s.get_x())
+            assert bits_equal(dev.get_P(0), s.get_P())
+            assert bits_equal(dev.get_pi(0), s.get_pi())
+        dev.close()
