@@ -31,7 +31,7 @@ BXH_ERR_DEVICE = -4
 SYMBOLS = [
     "bxh_last_error", "bxh_create", "bxh_destroy", "bxh_set_stream", "bxh_batch",
     "bxh_nwords", "bxh_rmax", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_set_pi", "bxh_get_pi",
-    "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset",
+    "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset", "bxh_reset_all",
     "bxh_order_create", "bxh_order_init", "bxh_order_init_masked", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
     "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time",
 ]
@@ -143,6 +143,7 @@ def lib():
         L.bxh_reset.argtypes = [C.c_void_p, C.c_int]
         L.bxh_order_init.argtypes = [C.c_void_p, C.c_int, i32p]
         L.bxh_order_create.argtypes = [C.c_void_p, C.c_int]
+        L.bxh_reset_all.argtypes = [C.c_void_p]
         L.bxh_order_init_masked.argtypes = [C.c_void_p, C.c_int, u8p, i32p]
         L.bxh_get_violated.argtypes = [C.c_void_p, C.c_int, i32p, i32p]
         L.bxh_sweep.argtypes = [C.c_void_p, C.POINTER(BxhSweepArgs), C.c_void_p]
@@ -274,6 +275,10 @@ class DeviceBatch:
 
     def reset(self, i):
         _check(self.L.bxh_reset(self.h, i))
+
+    def reset_all(self):
+        """Solver::reset() of every instance (P = pi = 0), stream-ordered."""
+        _check(self.L.bxh_reset_all(self.h))
 
     def order_create(self, order):
         """compute_order's constructor for every instance."""

@@ -1203,6 +1203,19 @@ bxh_reset(bxh_handle h, int inst)
     return BXH_OK;
 }
 
+// Solver::reset() of every instance, stream-ordered
+int
+bxh_reset_all(bxh_handle h)
+{
+    if (!h)
+        return fail(BXH_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = static_cast<size_t>(h->batch);
+    HIP_TRY(hipMemsetAsync(h->P.p, 0, B * h->nnzp * h->groups * h->fsize, h->stream));
+    HIP_TRY(hipMemsetAsync(h->pi.p, 0, B * h->m * h->fsize, h->stream));
+    return BXH_OK;
+}
+
 // compute_order's constructor (itm-common.hpp:640-658): `cycle` starts as
 // `none`; both lists are sized with the number of variables, m_order with
 // value-initialised pairs (which a `cycle` run meets before they are first

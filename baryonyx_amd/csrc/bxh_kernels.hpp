@@ -3133,11 +3133,52 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     bkmax = min(bkmax + c_size, r);
                 }
                 sel = bkmax - 1;
-                for (int i = bkmin; i <= bkmax; ++i)
-                    if (stop(Rv(i))) {
-                        sel = i - 1;
-                        break;
+                // The scan `for i = bkmin .. bkmax: stop at the first R[i] that
+                // stops` over the sorted row N.. N Z.. Z S.. S: entries of class
+                // N never stop, every zero flips the coin, the first S stops --
+                // the class borders come from two binary searches in the keys.
+                const unsigned long long K0 = order_key<Float>((Float)0, maximize);
+                int nN = 0, nNZ = 0;
+                {
+                    int lo = 0, hi = r; // first key >= K0
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (key_s[mid] < K0)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
                     }
+                    nN = lo;
+                    hi = r; // first key > K0
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (key_s[mid] <= K0)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    nNZ = lo;
+                }
+                int cur = bkmin;
+                if (cur <= bkmax) {
+                    bool stopped = false;
+                    if (cur < nN)
+                        cur = nN;
+                    while (!stopped && cur <= bkmax && cur < nNZ) {
+                        if (rng.coin())
+                            stopped = true;
+                        else
+                            ++cur;
+                    }
+                    if (!stopped && cur <= bkmax) {
+                        if (cur < r)
+                            stopped = true; // first S entry
+                        else
+                            stopped = stop(stale_s[r]); // R[r_size] (stale)
+                    }
+                    if (stopped)
+                        sel = cur - 1;
+                }
             }
 
             const Float one = 1, two = 2;

@@ -12,7 +12,10 @@ compute_order::run sweep (lib/src/itm-common.hpp:660-680,800-880) with the
 kappa of that restart (best_solution_recorder::reinit's kappa-improve cycle),
 P and pi carried over from the previous restart exactly as optimize_functor
 does (lib/src/itm-optimizer-common.hpp:649-663) -- i.e. m row updates per
-instance and step, the workload BASELINE.md section 2 timed on the CPU.  Workload at every N (weak
+instance and step, the workload BASELINE.md section 2 timed on the CPU.  Every
+8th restart starts a new solve (Solver::reset(): P = pi = 0): restarting from
+the same infeasible point otherwise multiplies pi by ~100 per restart and
+overflows (fp32 after 23 restarts, fp64 after ~150).  Workload at every N (weak
 scaling: fixed per-GPU work): BASELINE.json configs[1], an scpnrh1-shaped
 synthetic set-covering instance (1000 x 10000, 5 % density, inequalities-01
 path), 64 restarts per GPU; restarts are sharded over ranks with no data-path
@@ -39,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+RESET_EVERY = 8  # restarts per solve in the synthetic workload (see step())
 
 
 def parse():
@@ -93,6 +97,8 @@ def cpu_run(inst, params, float_type, seconds, nthreads):
         x0 = pack_bits(bast.astype(np.uint8))
         k = 0
         while time.perf_counter() < stop_at[0]:
+            if k % RESET_EVERY == 0:
+                s.reset()
             s.set_x(x0)
             s.order_init(params.order)
             s.sweep(kappa_cycle(params, k), delta, params.theta)
@@ -201,7 +207,15 @@ def main():
 
     def step(k):
         # one restart of every instance: x <- Bastert point, compute_order::init,
-        # one full sweep (P and pi carry over, as in optimize_functor)
+        # one full sweep.  P and pi carry over from restart to restart as in
+        # optimize_functor (itm-optimizer-common.hpp:658-663 never resets the
+        # Solver), but restarting from the same infeasible point each time makes
+        # pi grow a hundredfold per restart: every RESET_EVERY-th restart begins
+        # a new solve (Solver::reset(), P = pi = 0) so that any --steps stays
+        # finite in fp64 and fp32.  The first sweep after a reset is the
+        # tie-heaviest one (reduced costs == costs).
+        if k % RESET_EVERY == 0:
+            dev.reset_all()
         dev.set_x_all(x0)
         dev.order_init(params.order, sync=False)
         kap = np.full(args.batch, kappa_cycle(params, k))

@@ -159,6 +159,8 @@ int bxh_set_rng(bxh_handle h, int inst, uint32_t state);
 int bxh_get_rng(bxh_handle h, int inst, uint32_t* state);
 /* Solver::reset() (e.g. itm-solver-inequalities-01.cpp:109-113) */
 int bxh_reset(bxh_handle h, int inst);
+/* the same for every instance, enqueued on the stream (no synchronisation) */
+int bxh_reset_all(bxh_handle h);
 
 /* compute_order's constructor (itm-common.hpp:640-658) for every instance:
  * `order` is a bxh_order (solver_parameters::constraint_order, core:286-296);

@@ -80,6 +80,7 @@ struct HandleBase
     virtual int rmax() = 0;
     virtual double compute_delta(double theta) = 0;
     virtual void get_cost(double* out) = 0;
+    virtual void reset() = 0;
     virtual int get_qcost(std::int32_t* qptr, std::int32_t* qid, double* qfactor) = 0;
     virtual void get_x(std::uint64_t* w) = 0;
     virtual void set_x(const std::uint64_t* w) = 0;
@@ -144,6 +145,7 @@ struct Handle : HandleBase
         return static_cast<double>(
           orc::compute_delta<Float>(norm, static_cast<Float>(theta)));
     }
+    void reset() override { slv->reset(); }
     void get_cost(double* out) override
     {
         for (int i = 0; i != cs.n; ++i)
@@ -386,6 +388,11 @@ void
 orc_solver_get_cost(void* h, double* out)
 {
     H(h)->get_cost(out);
+}
+void
+orc_solver_reset(void* h)
+{
+    H(h)->reset();
 }
 int
 orc_solver_get_qcost(void* h, int32_t* qptr, int32_t* qid, double* qfactor)

@@ -80,6 +80,8 @@ int orc_solver_nwords(void* h); /* n/64 + 1 */
 int orc_solver_rmax(void* h);
 double orc_solver_compute_delta(void* h, double theta);
 void orc_solver_get_cost(void* h, double* out_n); /* normalised, as Float */
+/* Solver::reset(): P = pi = 0 */
+void orc_solver_reset(void* h);
 /* normalised quadratic costs as adjacency lists (quadratic_cost_type::indices /
  * quadratic_elements); null arrays: only the count is returned */
 int orc_solver_get_qcost(void* h, int32_t* qptr_n1, int32_t* qid, double* qfactor);

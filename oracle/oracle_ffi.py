@@ -109,6 +109,8 @@ def lib():
         L.orc_solver_compute_delta.argtypes = [C.c_void_p, C.c_double]
         L.orc_solver_compute_delta.restype = C.c_double
         L.orc_solver_get_cost.argtypes = [C.c_void_p, f64p]
+        L.orc_solver_reset.argtypes = [C.c_void_p]
+        L.orc_solver_reset.restype = None
         L.orc_solver_get_qcost.argtypes = [C.c_void_p, i32p, i32p, f64p]
         L.orc_solver_get_qcost.restype = C.c_int
         L.orc_solver_get_x.argtypes = [C.c_void_p, u64p]
@@ -229,6 +231,10 @@ class Solver:
         out = np.zeros(self.inst.n, np.float64)
         self.L.orc_solver_get_cost(self.h, _p(out, f64p))
         return out
+
+    def reset(self):
+        """Solver::reset(): P = pi = 0."""
+        self.L.orc_solver_reset(self.h)
 
     def qcost(self):
         """(q_ptr, q_id, q_factor) of the normalised quadratic costs, or None."""
