@@ -173,10 +173,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # one rank per GPU; BENCH_SHARE_GPU=1 (test rigs with one GPU) lets the ranks
+    # share device 0 and talk over gloo instead of RCCL
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
 
     from baryonyx_amd import _ffi
     from baryonyx_amd.driver import Params, compute_delta, normalize_costs
