@@ -405,7 +405,10 @@ bxh_create(const bxh_problem* pb,
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
-        while (groups < 4 && batch * groups * 2 <= cus && rmax / (groups * 2) >= 16)
+        // ... and only while every owner still gets a full round of 128 columns of
+        // the longest row: below that the exchange costs more than the split saves
+        // (measured: rows of 20 and of 120 elements run 10-20 % faster with one owner)
+        while (groups < 4 && batch * groups * 2 <= cus && rmax / (groups * 2) >= 128)
             groups *= 2;
         if (const char* eg = std::getenv("BXH_GROUPS")) {
             const int g = std::atoi(eg);
