@@ -433,18 +433,21 @@ uniform_u64(unsigned long long v) // a value every lane holds -> scalar register
     return bcast_first_u64(v);
 }
 
-// Tie filter: one bit per hashed key in an LDS bitmap of 2^16 bits.  A key whose
-// bit was already set MAY equal an earlier key of the row; two equal keys
-// always leave the later one flagged.
+// Tie filter: an LDS bitmap of 2^16 bits; a key sets two bits of ONE 32-bit word
+// (word and both positions from its hash) with a single atomic OR.  A key that
+// finds both already set MAY equal an earlier key of the row; of two equal keys
+// the later one always does (one atomic per key: no ordering between bits).
+// About one key in 2000 is flagged without being a duplicate at 500 keys.
 __device__ inline bool
 filter_insert(unsigned* bitmap, unsigned long long key)
 {
     unsigned x = (unsigned)(key >> 32) * 0x9E3779B1u + (unsigned)key * 0x85EBCA77u;
     x ^= x >> 15;
     x *= 0xC2B2AE3Du;
-    const unsigned i = x >> 16;
-    const unsigned bit = 1u << (i & 31);
-    return (atomicOr(&bitmap[i >> 5], bit) & bit) != 0u;
+    x ^= x >> 13;
+    const unsigned word = x >> 21;                      // 2048 words
+    const unsigned bits = (1u << (x & 31)) | (1u << ((x >> 5) & 31));
+    return (atomicOr(&bitmap[word], bits) & bits) == bits;
 }
 
 // Open-addressing insert of a non-zero key; returns true when the key was
