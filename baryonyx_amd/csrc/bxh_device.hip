@@ -514,6 +514,15 @@ bxh_create(const bxh_problem* pb,
                 for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e)
                     if (owner[pb->col[e]] == g)
                         sub_e.push_back(e);
+                // longest columns first: a chunk of 16 loads and adds as many
+                // 16-entry pieces as its longest column has, so like lengths
+                // share a chunk (the order inside an owner's part is free: values
+                // are exchanged by their position in the whole row)
+                std::stable_sort(sub_e.begin() + sub_ptr[static_cast<size_t>(g) * (m + 1) + k],
+                                 sub_e.end(), [&](int a, int b) {
+                                     return ((col_len[pb->col[a]] + 15) >> 4) >
+                                            ((col_len[pb->col[b]] + 15) >> 4);
+                                 });
                 const int len = static_cast<int>(sub_e.size()) -
                                 sub_ptr[static_cast<size_t>(g) * (m + 1) + k];
                 romax = std::max(romax, len);

@@ -433,11 +433,11 @@ uniform_u64(unsigned long long v) // a value every lane holds -> scalar register
     return bcast_first_u64(v);
 }
 
-// Tie filter: an LDS bitmap of 2^16 bits; a key sets two bits of ONE 32-bit word
-// (word and both positions from its hash) with a single atomic OR.  A key that
-// finds both already set MAY equal an earlier key of the row; of two equal keys
-// the later one always does (one atomic per key: no ordering between bits).
-// About one key in 2000 is flagged without being a duplicate at 500 keys.
+// Tie filter: an LDS bitmap of 2^16 bits; a key sets three bits of ONE 32-bit
+// word (word and positions from its hash) with a single atomic OR.  A key that
+// finds them all already set MAY equal an earlier key of the row; of two equal
+// keys the later one always does (one atomic per key: no ordering between
+// bits).  At 500 keys about one row in 40 flags a key that is no duplicate.
 __device__ inline bool
 filter_insert(unsigned* bitmap, unsigned long long key)
 {
@@ -446,7 +446,7 @@ filter_insert(unsigned* bitmap, unsigned long long key)
     x *= 0xC2B2AE3Du;
     x ^= x >> 13;
     const unsigned word = x >> 21;                      // 2048 words
-    const unsigned bits = (1u << (x & 31)) | (1u << ((x >> 5) & 31));
+    const unsigned bits = (1u << (x & 31)) | (1u << ((x >> 5) & 31)) | (1u << ((x >> 10) & 31));
     return (atomicOr(&bitmap[word], bits) & bits) == bits;
 }
 
