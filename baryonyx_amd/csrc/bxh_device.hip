@@ -898,8 +898,8 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->vcount.alloc(B));
     HIP_TRY(h->vflag.alloc(B * GG * m));
     HIP_TRY(h->status.alloc(B));
-    HIP_TRY(h->prof.alloc(B * 16));
-    HIP_TRY(hipMemset(h->prof.p, 0, B * 16 * sizeof(unsigned long long)));
+    HIP_TRY(h->prof.alloc(B * 32));
+    HIP_TRY(hipMemset(h->prof.p, 0, B * 32 * sizeof(unsigned long long)));
     HIP_TRY(h->kappa.alloc(B));
     HIP_TRY(h->active.alloc(B));
     HIP_TRY(hipMemset(h->P.p, 0, B * GG * nnzp * h->fsize));
@@ -1509,21 +1509,22 @@ bxh_kernel_time(bxh_handle h, double* total_ms, uint64_t* launches, int reset)
     return BXH_OK;
 }
 
-/* Diagnostic builds only (-DBXH_PROFILE): per-instance phase ticks
- * (100 MHz wall clock) accumulated by the sweep kernel; zeros otherwise. */
+/* Diagnostic builds only (-DBXH_PROFILE): per instance 16 phase accumulators,
+ * 4 barrier skews (last - first wave) and 4 waits of wave 0, in ticks of the
+ * 100 MHz wall clock; zeros otherwise. */
 int
-bxh_debug_profile(bxh_handle h, uint64_t* ticks_batch_x16, int reset)
+bxh_debug_profile(bxh_handle h, uint64_t* ticks_batch_x32, int reset)
 {
-    if (!h || !ticks_batch_x16)
+    if (!h || !ticks_batch_x32)
         return fail(BXH_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(ticks_batch_x16,
+    HIP_TRY(hipMemcpy(ticks_batch_x32,
                       h->prof.p,
-                      static_cast<size_t>(h->batch) * 16 * sizeof(unsigned long long),
+                      static_cast<size_t>(h->batch) * 32 * sizeof(unsigned long long),
                       hipMemcpyDeviceToHost));
     if (reset)
-        HIP_TRY(hipMemset(h->prof.p, 0, static_cast<size_t>(h->batch) * 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(h->prof.p, 0, static_cast<size_t>(h->batch) * 32 * sizeof(unsigned long long)));
     return BXH_OK;
 }
 

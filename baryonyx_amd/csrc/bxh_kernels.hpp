@@ -116,7 +116,7 @@ struct Prof
     unsigned long long acc[16];
     unsigned long long t;
 };
-#ifdef BXH_PROFILE
+#if defined(BXH_PROFILE) && !defined(BXH_NO_STAMPS)
 #define BXH_PSTAMP(pp, slot)                                                   \
     do {                                                                       \
         if (threadIdx.x == 0) {                                                \
@@ -130,7 +130,7 @@ struct Prof
     do {                                                                       \
     } while (0)
 #endif
-#ifdef BXH_PROFILE
+#if defined(BXH_PROFILE) && !defined(BXH_NO_STAMPS)
 #define BXH_STAMP(slot)                                                        \
     do {                                                                       \
         if (tid == 0) {                                                        \
@@ -143,6 +143,29 @@ struct Prof
 #define BXH_STAMP(slot)                                                        \
     do {                                                                       \
     } while (0)
+#endif
+
+// Profiling build: arrival skew of the waves at the row loop's barriers
+// (slots 0..3 of a second accumulator set; part_s[16..47] hold the stamps).
+#ifdef BXH_PROFILE
+#define BXH_BARRIER(id)                                                        \
+    do {                                                                       \
+        if ((tid & 63) == 0)                                                   \
+            part_s[16 + (id) * 8 + (tid >> 6)] = wall_clock64();               \
+        __syncthreads();                                                       \
+        if (tid == 0) {                                                        \
+            unsigned long long mn_ = ~0ull, mx_ = 0ull;                        \
+            for (int w_ = 0; w_ < (T >> 6); ++w_) {                            \
+                const unsigned long long v_ = part_s[16 + (id) * 8 + w_];      \
+                mn_ = v_ < mn_ ? v_ : mn_;                                     \
+                mx_ = v_ > mx_ ? v_ : mx_;                                     \
+            }                                                                  \
+            skew[id] += mx_ - mn_;                                             \
+            own[id] += mx_ - part_s[16 + (id) * 8];                            \
+        }                                                                      \
+    } while (0)
+#else
+#define BXH_BARRIER(id) __syncthreads()
 #endif
 
 struct DevSweep
@@ -2348,6 +2371,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const int l8 = tid & 7;
     Prof prof;
 #ifdef BXH_PROFILE
+    unsigned long long skew[4] = { 0, 0, 0, 0 }, own[4] = { 0, 0, 0, 0 };
     for (int i = 0; i < 16; ++i)
         prof.acc[i] = 0;
     prof.t = wall_clock64();
@@ -2681,7 +2705,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             }
         }
         BXH_STAMP(15);
-        __syncthreads();
+        BXH_BARRIER(0);
         BXH_STAMP(2);
         // Row exchange among the owners: every reduced cost travels as two
         // naturally aligned 8-byte granules {32 value bits, 32-bit tag}, both
@@ -2785,7 +2809,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // slots: clear
         for (int i = tid; i < 512; i += T)
             reinterpret_cast<uint4*>(htab)[i] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
+        BXH_BARRIER(1);
         if (it + 1 < nrows)
             fill_loc(x1, cur ^ 1);
         BXH_STAMP(3);
@@ -2886,7 +2910,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
             }
             BXH_STAMP(8);
-            __syncthreads();
+            BXH_BARRIER(2);
             BXH_STAMP(9);
             // Every wave then runs the same, wave-uniform selection logic on
             // scalar registers: no second barrier, no broadcast through LDS.
@@ -3059,7 +3083,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     stale_s[pos] = pos < nN ? repN : (pos < nN + nZ ? (Float)0 : -repN);
                 }
             }
-            __syncthreads();
+            BXH_BARRIER(3);
             BXH_STAMP(6);
             continue;
         }
@@ -3271,9 +3295,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     }
     BXH_STAMP(7);
 #ifdef BXH_PROFILE
-    if (tid == 0 && grp == 0)
+    if (tid == 0 && grp == 0) {
         for (int i = 0; i < 16; ++i)
-            st.prof[(size_t)inst * 16 + i] += prof.acc[i];
+            st.prof[(size_t)inst * 32 + i] += prof.acc[i];
+        for (int i = 0; i < 4; ++i) {
+            st.prof[(size_t)inst * 32 + 16 + i] += skew[i];
+            st.prof[(size_t)inst * 32 + 20 + i] += own[i];
+        }
+    }
 #endif
 
     if (tid == 0 && grp == 0) {

@@ -32,10 +32,13 @@ for step in range(4):
     dev.set_x_all(x0)
     dev.order_init(0, sync=False)
     dev.sweep(0.02 * (step + 1), delta, 0.5)
-    t = np.zeros((batch, 16), np.uint64)
+    t = np.zeros((batch, 32), np.uint64)
     L.bxh_debug_profile(dev.h, t.ctypes.data_as(C.POINTER(C.c_uint64)), 1)
-    tot = t.sum(axis=1).mean()
+    tot = t[:, :16].sum(axis=1).mean()
     ms, n = dev.kernel_time(reset=True)
     print(f"step {step}: kernel {ms/n:.2f} ms; ticks/instance {tot:.0f} (= {tot/100e3:.2f} ms @100MHz)")
     for i, nm in enumerate(names):
         print(f"   {nm:12s} {t[:, i].mean() / tot * 100:6.2f} %   {t[:, i].mean() / 100.0 / 1000:8.3f} us/row")
+    for i, nm in enumerate(["barrier rc-final", "barrier exchange", "barrier minima", "barrier affect"]):
+        print(f"   skew {nm:18s} last-first {t[:, 16 + i].mean() / 100.0 / 1000:6.3f} us/row   "
+              f"wave 0 waits {t[:, 20 + i].mean() / 100.0 / 1000:6.3f} us/row")
