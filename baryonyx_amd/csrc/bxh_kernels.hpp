@@ -2869,7 +2869,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 unsigned long long pending = __ballot(flagged[s2]);
-                while (pending) {
+                while (pending && !wtie) { // one confirmed tie settles the row
                     const int src = __ffsll((long long)pending) - 1;
                     pending &= pending - 1;
                     const unsigned long long fk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(
