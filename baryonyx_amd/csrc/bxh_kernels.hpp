@@ -536,7 +536,7 @@ pair_less(unsigned long long ka, int ia, unsigned long long kb, int ib)
 }
 
 template<typename Float>
-__device__ inline void
+__device__ __attribute__((noinline)) void
 run_merge_sort(const Float* val_by_id, // [n] reduced cost of row-local id
                int n,
                bool maximize,
@@ -756,7 +756,9 @@ lcg_jump(const unsigned* lcg_pow, unsigned state, int draws)
     return (unsigned)(x >= 0x7fffffffull ? x - 0x7fffffffull : x);
 }
 
-__device__ inline bool
+// (not inlined: the sort path is cold in tie-free sweeps, and its registers
+// would otherwise count against the row loop)
+__device__ __attribute__((noinline)) bool
 parallel_tie_shuffle(const unsigned long long* key_s,
                      int* id_s,
                      int r,
