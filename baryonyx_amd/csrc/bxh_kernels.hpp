@@ -734,6 +734,39 @@ rebuild_violated(const DevProblem& pb,
     return base;
 }
 
+// Sort of a short row (n <= blockDim.x, a few dozen elements) by counting: every
+// element reads all keys (LDS broadcast reads, independent of each other) and
+// its rank is the number of pairs (key, id) below its own -- the same order as
+// the bitonic / run-merge sorts (by value, ties by row-local id), without their
+// dependent compare-exchange steps.  key_tmp: n u64 of scratch.
+template<typename Float>
+__device__ inline void
+rank_sort_small(const Float* val_by_id,
+                int n,
+                bool maximize,
+                unsigned long long* key_tmp,
+                unsigned long long* key_out,
+                int* id_out)
+{
+    const int tid = threadIdx.x;
+    unsigned long long mine = ~0ull;
+    if (tid < n) {
+        mine = order_key<Float>(val_by_id[tid], maximize);
+        key_tmp[tid] = mine;
+    }
+    __syncthreads();
+    if (tid < n) {
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const unsigned long long kj = key_tmp[j];
+            rank += (kj < mine) || (kj == mine && j < tid);
+        }
+        key_out[rank] = mine;
+        id_out[rank] = tid;
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------
 // random_shuffle_unique (itm-common.hpp:117-131) for a whole workgroup: after
 // the sort every run of equal keys is shuffled with std::shuffle and the
@@ -1788,6 +1821,12 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     rng.s = st.status[inst].rng; // meaningful in thread 0 only
     const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
     double alg_bytes = 0.0; // thread 0 only
+    Prof prof;
+#ifdef BXH_PROFILE
+    for (int i = 0; i < 16; ++i)
+        prof.acc[i] = 0;
+    prof.t = wall_clock64();
+#endif
 
     if (tid == 0) {
         misc_s[MS_PICH] = 0;
@@ -1871,11 +1910,15 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         const int n2 = next_pow2(r < 2 ? 2 : r);
         if (tid == 0)
             misc_s[MS_TIE] = 0;
+        BXH_STAMP(0);
         __syncthreads();
+        BXH_STAMP(1);
 
         // ---- calculator_sort (every kind but the plain exhaustive one) -----
         if (zk != Z_EXHAUSTIVE) {
-            if (r > 1 && r <= 2 * T && r <= 1024) {
+            if (r > 1 && r <= T && r <= 160) {
+                rank_sort_small<Float>(val_s, r, maximize, key_run, key_s, id_s);
+            } else if (r > 1 && r <= 2 * T && r <= 1024) {
                 // wave-sorted runs + rank search: 2 barriers instead of ~25
                 Prof noprof;
                 noprof.t = 0;
@@ -1894,7 +1937,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                     misc_s[MS_TIE] = 1;
             __syncthreads();
             bool shuffled = false;
-            if (misc_s[MS_TIE] && r > 1 && r <= 2 * T && r <= 1024) {
+            if (misc_s[MS_TIE] && r > 64 && r <= 2 * T && r <= 1024) {
                 if (tid == 0) // the engine lives in thread 0 in this kernel
                     misc_s[MS_RNG] = (int)rng.s;
                 __syncthreads();
@@ -1918,9 +1961,11 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 id_s[i] = i;
         }
         __syncthreads();
+        BXH_STAMP(2);
         for (int i = tid; i < r; i += T)
             fz_s[i] = res_s[id_s[i]];
         __syncthreads();
+        BXH_STAMP(3);
 
         // ---- selection ------------------------------------------------------
         const int bkmin = cur.bmin, bkmax = cur.bmax;
@@ -1930,8 +1975,37 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         // and leaves at the first i, at or after the first such one, whose
         // successor R[i + 1] has a stopping value (R[r] as the reference's
         // array still holds it).
-        const bool par_select = r <= T && (zk == Z_LINEAR || zk == Z_UNCONSTRAINED_BB ||
-                                           zk == Z_UNCONSTRAINED_EXHAUSTIVE);
+        const bool scan_kind = zk == Z_LINEAR || zk == Z_UNCONSTRAINED_BB ||
+                               zk == Z_UNCONSTRAINED_EXHAUSTIVE;
+        // a row of fewer than 64 elements: the same scan inside wave 0, on
+        // ballots (no barrier): lane t stands for i = t - 1
+        const bool wave_select = scan_kind && r < 64;
+        if (wave_select && tid < 64) {
+            const int i = tid - 1; // -1 .. 62
+            const bool in = i < r;
+            const int f = (i >= 0 && i < r) ? fz_s[i] : 0;
+            int S = f; // inclusive scan over i = -1 .. (S_-1 = 0)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(S, off, 64);
+                if (tid >= off)
+                    S += o;
+            }
+            const Float nv = i + 1 < r ? val_s[id_s[i + 1]] : stale_s[i + 1 <= pb.rmax ? i + 1 : pb.rmax];
+            const unsigned long long valid = __ballot(in && bkmin <= S && S <= bkmax);
+            const unsigned long long stops = __ballot(in && (maximize ? nv < 0 : nv > 0));
+            int sel = -2;
+            if (valid) {
+                const int fv = __ffsll((long long)valid) - 1;         // lane of the first valid i
+                const unsigned long long after = stops & ~((1ull << fv) - 1ull);
+                const int leave = after ? __ffsll((long long)after) - 1 : r; // lane; r == i = r - 1
+                const unsigned long long upto = valid & (leave >= 63 ? ~0ull : ((2ull << leave) - 1ull));
+                sel = (63 - __clzll((long long)upto)) - 1; // lane -> i
+            }
+            if (tid == 0)
+                (misc_s + MS_WAVES)[34] = sel;
+        }
+        const bool par_select = !wave_select && r <= T && scan_kind;
         if (par_select) {
             const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
             int* wsum = misc_s + MS_WAVES; // per-wave totals, then the three results
@@ -1986,8 +2060,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         if (tid == 0) {
             alg_bytes += cur.rbytes;
             int sel = -2;
-            if (r > T && (zk == Z_LINEAR || zk == Z_UNCONSTRAINED_BB ||
-                          zk == Z_UNCONSTRAINED_EXHAUSTIVE)) {
+            if (r > T && scan_kind) {
                 // select_variables, :308-344 (reads R[i + 1] up to R[r])
                 auto Rv = [&](int i) -> Float { return i < r ? val_s[id_s[i]] : stale_s[i]; };
                 int sum = 0;
@@ -2005,7 +2078,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                     // (i + 1 == r: the reference adds the stale R[r].f and leaves)
                 }
             }
-            if (par_select)
+            if (par_select || wave_select)
                 sel = (misc_s + MS_WAVES)[34];
             misc_s[MS_SEL] = sel;
             misc_s[MS_SELMODE] = 0; // 1: B&B wanted, 2: exhaustive wanted
@@ -2100,6 +2173,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
             __syncthreads();
         }
 
+        BXH_STAMP(4);
         // ---- local_affect, :346-439: pi and d first ----------------------------
         if (tid == 0) {
             const int sel = misc_s[MS_SEL];
@@ -2121,6 +2195,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         }
         __syncthreads();
 
+        BXH_STAMP(5);
         // ---- every variable: x, P, then its repaired preference ------------
         {
             const int sel = misc_s[MS_SEL];
@@ -2152,6 +2227,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
             }
         }
         __syncthreads();
+        BXH_STAMP(6);
         // R as the reference leaves it (values by final position)
         for (int i = tid; i < r; i += T)
             stale_s[i] = val_s[id_s[i]];
@@ -2167,6 +2243,12 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
 
     const int cnt = rebuild_violated(
       pb, x_s, st.vflag + (size_t)inst * pb.m, out_list, misc_s + MS_WAVES);
+    BXH_STAMP(7);
+#ifdef BXH_PROFILE
+    if (tid == 0)
+        for (int i = 0; i < 16; ++i)
+            st.prof[(size_t)inst * 32 + i] += prof.acc[i];
+#endif
 
     if (tid == 0) {
         if (!keep)
