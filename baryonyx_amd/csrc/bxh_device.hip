@@ -80,6 +80,9 @@ struct bxh_handle_s
     int nb = 0;                // v2: 16-entry pieces per staged column
     int groups = 1;            // v2: workgroups (column owners) per instance
     int spare = 0;             // v2: spare staging slot set
+    int pipe = 0;              // v2: pipelined sweep, workgroups per instance (row chain + producers)
+    int lookahead = 2;         // v2: rows between a producer and the last finished row
+    int sw_chain = 0, sw_prod = 0; // v2: staging waves of the chain / a producer
     int romax = 0;             // longest per-owner part of a row
     unsigned epoch = 0;        // sweep launches so far (tags of the row exchange)
 
@@ -96,7 +99,8 @@ struct bxh_handle_s
     DevBuf<unsigned char> desc_cost; // cost of each descriptor's column (Float)
     DevBuf<unsigned> ownmask;        // [groups][2*nwords] x bits of each owner
     DevBuf<int> vwork, vpart;        // [batch][groups][m]
-    DevBuf<unsigned long long> xbuf; // [batch][2][rmax] reduced-cost exchange
+    DevBuf<unsigned long long> xbuf; // [batch][2][rmax] reduced-cost exchange (pipelined: [batch][ring][rmax])
+    DevBuf<unsigned long long> msg;  // [batch][m][2] pipelined sweep: finished rows
     DevBuf<unsigned> cnt;            // [2*batch] arrival counters + [1] error flag
     DevBuf<unsigned char> cost; // Float[n]
     DevBuf<double> row_bytes;   // [m]
@@ -251,12 +255,14 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
     }
     HIP_TRY(hipEventRecord(h->events[h->events_used].first, h->stream));
 #define BXH_LAUNCH(K)                                                          \
-    hipLaunchKernelGGL(K, dim3(h->batch * h->groups), dim3(h->threads),        \
+    hipLaunchKernelGGL(K, dim3(h->batch * (h->pipe ? h->pipe : h->groups)), dim3(h->threads), \
                        h->lds_bytes, h->stream, h->dp, h->ds, a)
     if (h->version == 2) {
 #define BXH_V2(PM, NPV)                                                        \
     do {                                                                       \
-        if (h->groups > 1)                                                     \
+        if (h->pipe)                                                           \
+            BXH_LAUNCH((bxh::sweep_kernel_v2<Float, PM, NPV, false, true>));   \
+        else if (h->groups > 1)                                                \
             BXH_LAUNCH((bxh::sweep_kernel_v2<Float, PM, NPV, true>));          \
         else                                                                   \
             BXH_LAUNCH((bxh::sweep_kernel_v2<Float, PM, NPV, false>));         \
@@ -420,6 +426,49 @@ bxh_create(const bxh_problem* pb,
     }
     if (pb->n_quad > 0) // c(j, x) reads every x bit: one owner
         groups = 1;
+    // Pipelined sweep (one row chain + producers per instance, one CSC copy):
+    // where the lock-step kernel would use 4 column owners, or on request
+    // (BXH_GROUPS=p2 / p3 / p4; BXH_PIPE=0 keeps the lock-step kernel).
+    {
+        int want = 0;
+        const char* eg = std::getenv("BXH_GROUPS");
+        const char* ep = std::getenv("BXH_PIPE");
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        if (eg && eg[0] == 'p')
+            want = std::atoi(eg + 1);
+        else if (!eg && groups == 4 && !(ep && ep[0] == '0'))
+            want = 4;
+        if (v2_ok && pb->n_quad == 0 && want >= 2 && want <= 4 && batch * want <= cus &&
+            rmax <= 1024 && n < 65536) {
+            const int np = cmax <= 64 ? 4 : (cmax <= 80 ? 5 : (cmax <= 96 ? 6 : 8));
+            const int fs = float_type == BXH_FLOAT ? 4 : 8;
+            int swc = 0, swp = 0;
+            for (int w = 8; w >= 1 && !swp; --w)
+                if (bxh::lds_plan2(m, h->nwords, rmax, rmax, fs, w * 16, np, false, 2, n).total <=
+                    160 * 1024)
+                    swp = w;
+            for (int w = 4; w >= 1 && !swc; --w)
+                if (bxh::lds_plan2(m, h->nwords, rmax, rmax, fs, w * 16, np, false, 1, n).total <=
+                    160 * 1024)
+                    swc = w;
+            if (swp >= 4 && swc >= 2) {
+                h->pipe = want;
+                h->sw_chain = swc;
+                h->sw_prod = swp;
+                if (const char* ew = std::getenv("BXH_PIPE_SW")) // experiments: fewer staging waves
+                    h->sw_prod = std::max(1, std::min(swp, std::atoi(ew)));
+                h->lookahead = 2;
+                if (const char* el = std::getenv("BXH_LOOKAHEAD"))
+                    h->lookahead = std::max(2, std::min(bxh::PIPE_RING - 1, std::atoi(el))); // (1 would dead-lock: the producers need the message of the row D + 1 back to load a row ahead)
+                groups = 1;
+            }
+        }
+        if (eg && eg[0] == 'p' && !h->pipe)
+            groups = 1;
+    }
     h->groups = groups;
 
     // Column owners.  Every owner should hold about r_k / groups entries of
@@ -746,6 +795,16 @@ bxh_create(const bxh_problem* pb,
         }
         // a spare set of slots (the overflow chunk of a row, summed in the same
         // pass as wave 0's own chunk) where it fits beside a full set of waves
+        if (h->pipe) {
+            const int fs = static_cast<int>(h->fsize);
+            const int lc = bxh::lds_plan2(m, h->nwords, rmax, rmax, fs, h->sw_chain * 16, np, false, 1, n).total;
+            const int lpz = bxh::lds_plan2(m, h->nwords, rmax, rmax, fs, h->sw_prod * 16, np, false, 2, n).total;
+            h->version = 2;
+            h->nb = np;
+            h->threads = 512;
+            h->spare = 0;
+            h->lds_bytes = static_cast<size_t>(std::max(lc, lpz));
+        }
         for (int t = tmax; t >= 128 && h->version != 2; t >>= 1)
             for (int spare = 1; spare >= 0; --spare) {
                 const bxh::LdsPlan2 lp2 = bxh::lds_plan2(m, h->nwords, rmax, romax,
@@ -762,8 +821,9 @@ bxh_create(const bxh_problem* pb,
             }
     }
     if (std::getenv("BXH_DEBUG"))
-        std::fprintf(stderr, "bxh: kernel v%d threads=%d lds=%zu np=%d groups=%d\n", h->version,
-                     h->threads, h->lds_bytes, h->nb, groups);
+        std::fprintf(stderr, "bxh: kernel v%d threads=%d lds=%zu np=%d groups=%d pipe=%d (chain %d, producer %d staging waves, lookahead %d)\n",
+                     h->version, h->threads, h->lds_bytes, h->nb, groups, h->pipe, h->sw_chain,
+                     h->sw_prod, h->lookahead);
     if (h->version != 2 && groups > 1)
         return fail(BXH_ERR_UNSUPPORTED, "instance does not fit the staged kernel's LDS plan");
 
@@ -861,13 +921,19 @@ bxh_create(const bxh_problem* pb,
 
     const size_t B = static_cast<size_t>(batch);
     const size_t GG = static_cast<size_t>(groups);
+    const size_t WG = static_cast<size_t>(h->pipe ? h->pipe : groups); // workgroups per instance
     HIP_TRY(h->P.alloc(B * GG * nnzp * h->fsize));
     const size_t LC = static_cast<size_t>(std::max(m, n));
     h->lcap = static_cast<int>(LC);
-    HIP_TRY(h->vwork.alloc(B * GG * LC));
+    HIP_TRY(h->vwork.alloc(B * WG * LC));
     HIP_TRY(h->vpart.alloc(B * GG * m));
-    HIP_TRY(h->xbuf.alloc(B * 2 * rmax * 2));
-    HIP_TRY(hipMemset(h->xbuf.p, 0, B * 2 * rmax * 2 * sizeof(unsigned long long)));
+    {
+        const size_t slots = h->pipe ? static_cast<size_t>(bxh::PIPE_RING) : 2;
+        HIP_TRY(h->xbuf.alloc(B * slots * rmax * 2));
+        HIP_TRY(hipMemset(h->xbuf.p, 0, B * slots * rmax * 2 * sizeof(unsigned long long)));
+        HIP_TRY(h->msg.alloc(B * static_cast<size_t>(m) * 2));
+        HIP_TRY(hipMemset(h->msg.p, 0, B * static_cast<size_t>(m) * 2 * sizeof(unsigned long long)));
+    }
     HIP_TRY(h->cnt.alloc(2 * B + 1));
     HIP_TRY(hipMemset(h->cnt.p, 0, (2 * B + 1) * sizeof(unsigned)));
     HIP_TRY(h->pi.alloc(B * m * h->fsize));
@@ -978,6 +1044,22 @@ bxh_create(const bxh_problem* pb,
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, true>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, false>));
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 5, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 5, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 5, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 5, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, false, true>));
+            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, false, true>));
         }
 #undef BXH_SET_LDS
     }
@@ -990,6 +1072,10 @@ bxh_create(const bxh_problem* pb,
     dp.groups = groups;
     dp.romax = romax;
     dp.spare = h->spare;
+    dp.pipe = h->pipe;
+    dp.lookahead = h->lookahead;
+    dp.sw_chain = h->sw_chain;
+    dp.sw_prod = h->sw_prod;
     dp.sub_ptr = h->sub_ptr.p;
     dp.sub_e = h->sub_e.p;
     dp.sub_desc = h->sub_desc.p;
@@ -1050,6 +1136,7 @@ bxh_create(const bxh_problem* pb,
     ds.vpart = h->vpart.p;
     ds.xbuf = h->xbuf.p;
     ds.cnt = h->cnt.p;
+    ds.msg = h->msg.p;
 
     *out = guard.release();
     return BXH_OK;
@@ -1416,12 +1503,15 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
                                h->stream));
         s.active = h->active.p;
     }
-    if (h->groups > 1) { // arrival counters of the cooperating workgroups
+    if (h->groups > 1 || h->pipe) { // arrival counters of the cooperating workgroups
         HIP_TRY(hipMemsetAsync(h->cnt.p, 0, 2 * static_cast<size_t>(h->batch) * sizeof(unsigned),
                                h->stream));
-        if ((++h->epoch & 0x1ffffu) == 0) // tag space wrapped: forget old granules
+        if ((++h->epoch & 0x1ffffu) == 0) { // tag space wrapped: forget old granules
             HIP_TRY(hipMemsetAsync(h->xbuf.p, 0, h->xbuf.count * sizeof(unsigned long long),
                                    h->stream));
+            HIP_TRY(hipMemsetAsync(h->msg.p, 0, h->msg.count * sizeof(unsigned long long),
+                                   h->stream));
+        }
     }
     s.epoch = h->epoch;
     if (need_prep) { // the sorts of the infeasibility / lagrangian orders
@@ -1462,7 +1552,7 @@ bxh_status_sync(bxh_handle h, bxh_status* out)
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rc = drain_events(h))
         return rc;
-    if (h->groups > 1 || h->version == 3) {
+    if (h->groups > 1 || h->version == 3 || h->pipe) {
         unsigned err = 0;
         HIP_TRY(hipMemcpy(&err, h->cnt.p + 2 * h->batch, sizeof err, hipMemcpyDeviceToHost));
         if (err == 2u)

@@ -30,6 +30,9 @@ struct DevProblem
     int groups;   // workgroups (column owners, column j -> j % groups) per instance
     int romax;    // longest per-owner part of a row
     int spare;    // 1: a spare set of 16 staging slots exists (overflow chunk)
+    int pipe;     // pipelined sweep: workgroups per instance (1 row chain + producers), 0 = off
+    int lookahead; // pipelined sweep: a producer works on the row D positions past the last finished one
+    int sw_chain, sw_prod; // pipelined sweep: waves with staging slots in the chain / a producer
     int cmax;     // longest column (real entries)
     int kind;     // bxh_kind
     int maximize; // 0 / 1
@@ -97,6 +100,7 @@ struct DevState
     int* vpart;          // [batch][groups][m] per-owner row activities
     unsigned long long* xbuf; // [batch][2][rmax][2] tagged halves of the row's reduced costs
     unsigned* cnt;       // [batch] row arrivals, [batch] sweep-end arrivals, [1] error
+    unsigned long long* msg; // [batch][m][2] pipelined sweep: tagged pi of every finished row position
     // compute_order's second list and scratch (itm-common.hpp:627-915)
     int lcap;            // capacity of the row lists: max(m, n)
     int2* mlist;         // [batch][lcap] m_order = {row, infeasibility}
@@ -1002,7 +1006,9 @@ enum
     MS_SELMODE = 5, // 0: none up, 1: all up, 2: up iff key <= threshold
     MS_D = 8,      // Float d (8 bytes reserved)
     MS_THR = 10,   // u64 threshold key (8 bytes)
-    MS_WAVES = 16  // 64 ints of scratch (also the per-wave partials below)
+    MS_WAVES = 16, // 64 ints of scratch (also the per-wave partials below)
+    MS_LCNT = 80,  // pipelined sweep: late entries of the row in either descriptor buffer (2 ints)
+    MS_DEAD = 82   // pipelined sweep: a partner timed out, stop polling
 };
 
 // Row order of an instance this sweep: 0 none, 1 reversing, 2 random_sorting,
@@ -2268,12 +2274,24 @@ struct LdsPlan2
 {
     int off_pi, off_x, off_val, off_sp, off_cs, off_pe, off_col, off_cost, off_pown, off_spi,
       off_oidx, off_loc, off_stale, off_misc, off_part, off_union, stage_i_off, total;
+    // pipelined sweep (role 1: row chain, role 2: producer)
+    int off_mark, off_map, off_flag, off_lnp, off_markl, off_newp, off_patch, off_htab;
 };
+
+template<bool V>
+struct PipeScope // compile-time scope of a P load
+{
+    static constexpr bool value = V;
+};
+constexpr int PIPE_RING = 4; // row slots of the producers' value ring (> lookahead)
 
 // The row descriptors (cs, pe, col, cost, oidx, loc) are double buffered: the
 // one of row it + 1 is written while the loads of row it are in flight.
+// role 0: the lock-step kernel; role 1 / 2: the row chain / a producer of the
+// pipelined sweep (n = number of variables: one 16-bit mark per column).
 __host__ __device__ inline LdsPlan2
-lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, bool mw)
+lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, bool mw,
+          int role = 0, int n = 0)
 {
     auto al = [](int v) { return (v + 15) & ~15; };
     LdsPlan2 p;
@@ -2281,11 +2299,14 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
     p.off_pi = o;
     o = al(o + (m + 1) * fsize); // + one zero entry read through column padding
     p.off_x = o;
-    o = al(o + nwords * 8);
+    if (role != 2)
+        o = al(o + nwords * 8);
     p.off_val = o;
-    o = al(o + rmax * fsize);
+    if (role != 2)
+        o = al(o + rmax * fsize);
     p.off_sp = o;
-    o = al(o + romax * fsize);
+    if (role == 0) // (the chain's late waves and the producers combine in registers)
+        o = al(o + romax * fsize);
     p.off_cs = o;
     o = al(o + 2 * romax * 8);
     p.off_pe = o;
@@ -2295,7 +2316,8 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
     p.off_cost = o;
     o = al(o + 2 * romax * fsize);
     p.off_pown = o; // the row's own P entries after the decay
-    o = al(o + romax * fsize);
+    if (role != 2)
+        o = al(o + romax * fsize);
     p.off_spi = p.off_val; // one owner: the pi sums sit in val_s until combined
     p.off_oidx = o;
     p.off_loc = o;
@@ -2308,18 +2330,47 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
         o = al(o + 2 * rmax * 2);
     }
     p.off_stale = o;
-    o = al(o + (rmax + 1) * fsize);
+    if (role != 2)
+        o = al(o + (rmax + 1) * fsize);
     p.off_misc = o;
     o = al(o + 96 * 4);
     p.off_part = o; // partial reductions of the sort-free selection
-    o = al(o + (64 + 8) * 8);
+    if (role != 2)
+        o = al(o + (64 + 8) * 8);
+    p.off_mark = p.off_map = p.off_flag = p.off_lnp = p.off_markl = p.off_newp = p.off_patch = o;
+    if (role == 1) {
+        p.off_markl = o; // entry index of column j in the row that marked it
+        o = al(o + n * 2);
+        p.off_newp = o; // what affect stored for every entry of the row
+        o = al(o + rmax * fsize);
+        p.off_patch = o; // late entry -> {entry of the previous row in the same column or -1,
+                         //                its position in the column}
+        o = al(o + 2 * rmax * 4);
+    }
+    if (role != 0) {
+        p.off_mark = o; // code (1..255, by position mod 255) of the last row that held column j
+        o = al(o + n);
+        p.off_map = o; // chain: the row's late entries; producer: entry or -1
+        o = al(o + 2 * rmax * 2);
+        p.off_flag = o; // chain: 1 = the entry's column is summed here
+        if (role == 1)
+            o = al(o + 2 * rmax);
+        p.off_lnp = o; // chain: largest piece count of every late chunk
+        if (role == 1)
+            o = al(o + 2 * ((rmax + 15) / 16) * 4);
+    }
+    p.off_htab = o;
+    if (role == 1) // the tie filter's bitmap: not over the staging slots, which the late
+        o = al(o + 512 * 16); // waves may still be reading when the other waves clear it
     p.off_union = o;
+    if (role != 1)
+        p.off_htab = o;
     // staging: per slot np*16 (+2) Float and np*16 (+4) 16-bit row indices
     const int stage_p = al(slots * (np * 16 + 2) * fsize);
     const int stage = stage_p + al(slots * (np * 16 + 4) * 2);
     p.stage_i_off = stage_p;
     const int n2 = next_pow2(rmax < 64 ? 64 : rmax); // whole 64-entry runs
-    const int sortb = 2 * (al(n2 * 8) + al(n2 * 4)); // runs + merged output
+    const int sortb = role == 2 ? 0 : 2 * (al(n2 * 8) + al(n2 * 4)); // runs + merged output
     o = al(o + (stage > sortb ? stage : sortb));
     p.total = o;
     return p;
@@ -2330,15 +2381,32 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
 // bit of that column; every workgroup keeps its own copy of pi, of the row's
 // reduced costs (exchanged once per row through L2) and of the engine, and
 // takes the same selection decisions from them.
-template<typename Float, bool PM1, int NP, bool MW>
+//
+// PIPE: the pipelined sweep.  Row k + 1 reads what row k wrote only through
+// the columns the two rows share: pi_k enters the sums of the columns of row
+// k alone, and so do the P entries row k changed.  The reduced cost of a
+// column of row p is therefore final as soon as the last row before p that
+// holds the column is finished -- on average c_j^-1 * m rows earlier.  One
+// workgroup per instance (the row chain, grp 0) runs select / affect row
+// after row and only sums the columns that one of the previous `lookahead`
+// rows holds (the late columns, ~5 % per row of look-ahead at the scpnrh
+// shape); pb.pipe - 1 producer workgroups run `lookahead` rows ahead of it,
+// sum the other columns exactly as above and hand the reduced costs over
+// through a ring of tagged granules in L2 (never a round trip: the chain
+// publishes {row finished, pi_k} messages and does not wait for anybody but
+// the values of the row it is at).  One CSC copy / P array per instance
+// (pb.groups == 1 layout).  Every sum keeps its order, so the results stay
+// bit-identical to the lock-step kernels'.
+template<typename Float, bool PM1, int NP, bool MW, bool PIPE = false>
 __global__ __launch_bounds__(512) void
 sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 {
+    static_assert(!(MW && PIPE), "the pipelined sweep has one P array per instance");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int LR = 2;
-    const int NG = MW ? pb.groups : 1;
+    const int NG = MW ? pb.groups : (PIPE ? pb.pipe : 1);
     int inst = blockIdx.x, grp = 0;
-    if (MW) {
+    if (MW || PIPE) {
         const int b = blockIdx.x, ninst = gridDim.x / NG;
         if ((ninst & 7) == 0) {
             // blocks 8 apart share an XCD under round-robin dispatch: keep the
@@ -2354,12 +2422,16 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         return;
 
     const int tid = threadIdx.x, T = blockDim.x;
-    const int G = ((T >> 6) + pb.spare) * 8 * LR; // staging slots: 8 * LR columns per wave (+ a spare set)
+    const int role = PIPE ? (grp == 0 ? 1 : 2) : 0;
+    const int SW = PIPE ? (grp == 0 ? pb.sw_chain : pb.sw_prod) : (T >> 6); // waves with staging slots
+    const int G = PIPE ? SW * 8 * LR
+                       : ((T >> 6) + pb.spare) * 8 * LR; // staging slots: 8 * LR columns per wave (+ a spare set)
     constexpr int SP = NP * 16 + 2; // Float entries of a P slot (16-byte rows)
     constexpr int SI = NP * 16 + 4; // 16-bit entries of an index slot (8-byte rows)
     typedef Float Float2 __attribute__((ext_vector_type(2)));
     const LdsPlan2 lp =
-      lds_plan2(pb.m, pb.nwords, pb.rmax, MW ? pb.romax : pb.rmax, (int)sizeof(Float), G, NP, MW);
+      lds_plan2(pb.m, pb.nwords, pb.rmax, MW ? pb.romax : pb.rmax, (int)sizeof(Float), G, NP, MW,
+                role, pb.n);
     Float* pi_s = (Float*)(smem + lp.off_pi);
     unsigned* x_s = (unsigned*)(smem + lp.off_x);
     Float* val_s = (Float*)(smem + lp.off_val);
@@ -2385,7 +2457,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     int* id_s = (int*)(smem + lp.off_union + ((n2max * 8 + 15) & ~15));
     // tie-detection table of the sort-free path: 2 * n2max 64-bit slots, over
     // the same bytes (the two paths never run for the same row)
-    unsigned long long* htab = (unsigned long long*)(smem + lp.off_union);
+    unsigned long long* htab = (unsigned long long*)(smem + lp.off_htab);
     unsigned long long* part_s = (unsigned long long*)(smem + lp.off_part);
     const int sort_half = ((n2max * 8 + 15) & ~15) + ((n2max * 4 + 15) & ~15);
     unsigned long long* key_run = (unsigned long long*)(smem + lp.off_union + sort_half);
@@ -2394,8 +2466,16 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const bool maximize = pb.maximize != 0;
     const int kind = pb.kind;
 
-    Float* P = (Float*)st.P + ((size_t)inst * NG + grp) * pb.nnzp;
-    const unsigned short* crow = pb.col_row16 + (size_t)grp * pb.nnzp;
+    Float* P = (Float*)st.P + (MW ? ((size_t)inst * NG + grp) : (size_t)inst) * pb.nnzp;
+    const unsigned short* crow = pb.col_row16 + (MW ? (size_t)grp * pb.nnzp : (size_t)0);
+    // pipelined sweep: column marks, late list / early map, flags
+    unsigned char* const mark_s = (unsigned char*)(smem + lp.off_mark);
+    short* const map_b = (short*)(smem + lp.off_map);
+    unsigned char* const flag_b = (unsigned char*)(smem + lp.off_flag);
+    int* const lnp_b = (int*)(smem + lp.off_lnp);
+    unsigned short* const markl_s = (unsigned short*)(smem + lp.off_markl);
+    Float* const newp_s = (Float*)(smem + lp.off_newp);
+    short2* const patch_b = (short2*)(smem + lp.off_patch);
     unsigned* const cnt_row = st.cnt + inst;
     unsigned* const cnt_end = st.cnt + gridDim.x / NG + inst;
     unsigned* const err_word = st.cnt + 2 * (gridDim.x / NG);
@@ -2409,7 +2489,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     int* vlist = use_m ? st.mrun + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
     int* out_list = keep ? st.slist + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
     // several owners: each works on a private copy of the row list
-    int* vrows = MW ? st.vwork + ((size_t)inst * NG + grp) * st.lcap : vlist;
+    int* vrows = (MW || PIPE) ? st.vwork + ((size_t)inst * NG + grp) * st.lcap : vlist;
     const Float* cost = (const Float*)pb.cost;
 
     const Float kappa = (Float)a.kappa[inst];
@@ -2425,31 +2505,39 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         pi_s[i] = pig[i];
     if (tid == 0)
         pi_s[pb.m] = 0; // read through the padding of the staged columns
-    for (int i = tid; i < 2 * pb.nwords; i += T)
-        x_s[i] = xg[i];
-    for (int i = tid; i <= pb.rmax; i += T)
-        stale_s[i] = staleg[i];
+    if (role != 2) {
+        for (int i = tid; i < 2 * pb.nwords; i += T)
+            x_s[i] = xg[i];
+        for (int i = tid; i <= pb.rmax; i += T)
+            stale_s[i] = staleg[i];
+    }
+    if (PIPE)
+        for (int i = tid; i < pb.n; i += T)
+            mark_s[i] = 0;
 
     MinStd rng;
     rng.s = st.status[inst].rng; // meaningful in thread 0 only
     const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
     double alg_bytes = 0.0; // thread 0 only
 
-    if (MW) {
+    if (MW || PIPE) {
         for (int i = tid; i < nrows; i += T)
             vrows[i] = vlist[i];
         __syncthreads();
     }
     if (tid == 0) {
+        if (PIPE) {
+            misc_s[MS_LCNT] = misc_s[MS_LCNT + 1] = 0;
+            misc_s[MS_DEAD] = 0;
+        }
         misc_s[MS_PICH] = 0;
         if (ord == 2 || ord == 7)
             rng.shuffle(vrows, (unsigned)nrows);
         misc_s[MS_RNG] = (int)rng.s;
     }
     __syncthreads();
-    if (MW && ord == 7 && grp == 0) // pi_sign_change keeps the shuffled R
-        for (int i = tid; i < nrows; i += T)
-            vlist[i] = vrows[i];
+    // (pi_sign_change keeps the shuffled R: written back behind the row loop,
+    // when every partner has copied the list)
     rng.s = (unsigned)misc_s[MS_RNG];
 
     const int l8 = tid & 7;
@@ -2635,8 +2723,419 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(st.xbuf + (size_t)inst * 2 * pb.rmax * 2), 0, MW ? 2 * pb.rmax * 16 : 0, 0x00020000);
+      (void*)(st.xbuf + (size_t)inst * (PIPE ? PIPE_RING : 2) * pb.rmax * 2), 0,
+      MW ? 2 * pb.rmax * 16 : (PIPE ? PIPE_RING * pb.rmax * 16 : 0), 0x00020000);
 
+    // ---- pipelined sweep ---------------------------------------------------
+    // messages of the row chain: position q (1-based) -> {pi of its row, tag}
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(st.msg + (PIPE ? (size_t)inst * pb.m * 2 : (size_t)0)), 0, PIPE ? pb.m * 16 : 0, 0x00020000);
+    const int D = pb.lookahead;
+    // Marks: one byte per column, the code of the last row position that held
+    // it (0: none yet).  A column of the row at position q is late when one
+    // of the D previous positions marked it.  Codes repeat every 255
+    // positions: a stale mark can only make an early column late, which both
+    // sides decide alike and which is always safe (the chain then sums a
+    // column whose rows are all finished).
+    auto code_of = [](int q_) -> int { return q_ % 255 + 1; };
+    auto is_late = [&](int mk, int q_) -> bool {
+        bool late = false;
+        for (int d_ = 1; d_ <= D; ++d_)
+            late = late || (q_ - d_ >= 1 && mk == code_of(q_ - d_));
+        return late;
+    };
+    const int LNPW = (pb.rmax + 15) / 16;
+    auto tag_of = [&](int q_) -> unsigned { return ((a.epoch & 0x1ffffu) << 15) | (unsigned)q_; };
+    // a granule pair {low half, tag, high half, tag}: polled until both tags
+    // are the expected one (bounded; one time-out stops all polling)
+    auto poll_pair = [&](const __amdgpu_buffer_rsrc_t& rs_, unsigned off, unsigned tag, v4u g) -> Float {
+        long spins = 0;
+        while (!(g.y == tag && g.w == tag)) {
+            if (__hip_atomic_load(&misc_s[MS_DEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 2000000L) { // a partner is missing: give up loudly
+                __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&misc_s[MS_DEAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                break;
+            }
+            g = __builtin_amdgcn_raw_buffer_load_b128(rs_, off, 0, 16);
+        }
+        const unsigned long long bits = (unsigned long long)g.x | ((unsigned long long)g.z << 32);
+        return (Float)__longlong_as_double((long long)bits);
+    };
+    auto pair_of = [&](Float v, unsigned tag) -> v4u {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong((double)v);
+        const v4u g = { (unsigned)bits, tag, (unsigned)(bits >> 32), tag };
+        return g;
+    };
+    // chunk position t -> row entry through a map (-1 / past cnt: no column)
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)P, 0, PIPE ? (int)((unsigned)pb.nnzp * (unsigned)sizeof(Float)) : 0, 0x00020000);
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    // DEV: device-scope (sc1) loads -- what the producers read was stored by
+    // another CU.  A compile-time choice: a run-time one makes the compiler
+    // wait for every load before it issues the next.
+    auto load_p2 = [&](unsigned byte_off, auto dev) -> Float2 { // 2 entries of P
+        constexpr int AUX = decltype(dev)::value ? 16 : 0;
+        Float2 out;
+        if (sizeof(Float) == 8) {
+            const v4u w = __builtin_amdgcn_raw_buffer_load_b128(prsrc, byte_off, 0, AUX);
+            __builtin_memcpy(&out, &w, sizeof out);
+        } else {
+            const v2u w = __builtin_amdgcn_raw_buffer_load_b64(prsrc, byte_off, 0, AUX);
+            __builtin_memcpy(&out, &w, sizeof out);
+        }
+        return out;
+    };
+    typedef PipeScope<true> DevScope;
+    typedef PipeScope<false> CuScope;
+    auto store_p = [&](unsigned slot, Float v) { // device-scope (write-through) store of one entry
+        if (sizeof(Float) == 8) {
+            v2u w;
+            __builtin_memcpy(&w, &v, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(w, prsrc, slot * 8u, 0, 16);
+        } else {
+            unsigned w;
+            __builtin_memcpy(&w, &v, 4);
+            __builtin_amdgcn_raw_buffer_store_b32(w, prsrc, slot * 4u, 0, 16);
+        }
+    };
+    // (direct: map[t] is t or -1 -- a producer's map -- so the descriptor is
+    // read next to the map entry, not behind it: one LDS round trip, which is
+    // slow while the other waves are summing)
+    // No branch per lane: a lane without a column loads from past the end of
+    // the buffers (nothing is fetched, zeros come back) and stages those zeros
+    // in a slot nobody reads.  With the loads and the LDS writes under a
+    // per-lane branch the compiler assumes loads whose staging was "skipped"
+    // still pending and waits for every load before it issues the next one.
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)crow, 0, PIPE ? (int)((unsigned)pb.nnzp * 2u) : 0, 0x00020000);
+    auto issue_m = [&](const int2* cs_r, const short* map, int cnt_, int chunk_, int npm_,
+                       auto dev, bool direct = false) {
+        // all addresses first, then all loads: where the compiler reuses a
+        // register of the previous chunk for an address it waits for that
+        // chunk's (long finished) load -- once, in front of the loads, not
+        // between them
+        unsigned qa[LR][NP], qi[LR][NP]; // byte offsets into P / into the row indices
+#pragma unroll
+        for (int h = 0; h < LR; ++h) {
+            const int t = chunk_ * CW + h * 8 + g8;
+            const int tt = min(t, cnt_ - 1);
+            const int l = t < cnt_ ? (int)map[tt] : -1;
+            const int2 csd = cs_r[tt];
+            const int2 cs = direct ? csd : cs_r[max(l, 0)];
+            const unsigned last = (unsigned)((cs.y & 0xffff) >> 4) - 1u;
+            const unsigned q0 = (unsigned)cs.x + 2u * (unsigned)l8;
+#pragma unroll
+            for (int b = 0; b < NP; ++b) {
+                const unsigned q = l >= 0 ? q0 + (min((unsigned)b, last) << 4) : 0x0ffffff0u;
+                qa[h][b] = q * (unsigned)sizeof(Float);
+                qi[h][b] = q * 2u;
+            }
+        }
+        // (opaque to the compiler, or it computes every address again next to its load)
+#pragma unroll
+        for (int h = 0; h < LR; ++h)
+#pragma unroll
+            for (int b = 0; b < NP; ++b)
+                asm volatile("" : "+v"(qa[h][b]), "+v"(qi[h][b]));
+#pragma unroll
+        for (int h = 0; h < LR; ++h) {
+#pragma unroll
+            for (int b = 0; b < NP; ++b) {
+                if (b < npm_) { // wave-uniform
+                    regP[h][b] = load_p2(qa[h][b], dev);
+                    regI[h][b] = __builtin_amdgcn_raw_buffer_load_b32(irsrc, qi[h][b], 0, 0);
+                }
+            }
+        }
+    };
+    auto stage_m = [&](const short* map, int cnt_, int chunk_, int npm_) {
+#pragma unroll
+        for (int h = 0; h < LR; ++h) {
+            Float* dp = wst_p + (h * 8 + g8) * SP + 2 * l8;
+            unsigned short* di = wst_i + (h * 8 + g8) * SI + 2 * l8;
+#pragma unroll
+            for (int b = 0; b < NP; ++b) {
+                if (b < npm_) {
+                    *reinterpret_cast<Float2*>(dp + b * 16) = regP[h][b];
+                    *reinterpret_cast<unsigned*>(di + b * 16) = regI[h][b];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // lanes 0-15 add the P entries and lanes 16-31 the pi entries of one
+    // staged column each, strictly in CSC order (as the lock-step kernel);
+    // returns the lane's sum and leaves the decayed own entry in *dec_out
+    // (row chain: a column loaded before the previous row's affect first takes
+    // that row's new entry, patch[t] = the entry's index in the previous row)
+    auto sum_m = [&](const int2* cs_r, const int* pe_r, const short* map, int cnt_, int chunk_,
+                     int& l_out, Float& dec_out, const short2* patch = nullptr,
+                     bool direct = false) -> Float {
+        const int lane5 = lane & 31;
+        const int u = lane5 & (CW - 1);
+        const bool is_pi = lane5 >= CW;
+        const int t = chunk_ * CW + u;
+        const int tt = min(t, cnt_ - 1);
+        const int l = (lane < 32 && t < cnt_) ? (int)map[tt] : -1;
+        const int2 csd = cs_r[tt];
+        const int ped = pe_r[tt];
+        l_out = l;
+        Float acc = 0;
+        if (l >= 0) {
+            const int2 cs = direct ? csd : cs_r[l];
+            const int cpad = cs.y & 0xffff;
+            if (!is_pi) { // P[e] *= theta for this row's entry
+                if (patch) {
+                    const short2 pp = patch[t];
+                    if (pp.x >= 0)
+                        wst_p[u * SP + pp.y] = newp_s[pp.x];
+                }
+                Float* pk = wst_p + u * SP + ((direct ? ped : pe_r[l]) - cs.x);
+                const Float dec = *pk * theta; // (stored to HBM by affect)
+                *pk = dec;
+                dec_out = dec;
+            }
+            const Float2* sp2 = reinterpret_cast<const Float2*>(wst_p + u * SP);
+            const uint2* si2 = reinterpret_cast<const uint2*>(wst_i + u * SI);
+            for (int i0 = 0; i0 < cpad; i0 += 16) {
+                Float v[16];
+                unsigned sg[8]; // 16 packed 16-bit indices
+                if (is_pi || PM1) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint2 w = si2[(i0 >> 2) + b];
+                        sg[2 * b] = w.x;
+                        sg[2 * b + 1] = w.y;
+                    }
+                }
+                if (is_pi) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        v[2 * b] = pi_s[sg[b] & 0x7fff];
+                        v[2 * b + 1] = pi_s[(sg[b] >> 16) & 0x7fff];
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const Float2 w = sp2[(i0 >> 1) + b];
+                        v[2 * b] = w.x;
+                        v[2 * b + 1] = w.y;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    Float term = v[b];
+                    if (PM1) {
+                        const unsigned neg = (sg[b >> 1] >> ((b & 1) ? 31 : 15)) & 1u;
+                        term = neg ? -term : term;
+                    }
+                    acc += term;
+                }
+            }
+        }
+        return acc;
+    };
+
+    if (PIPE && grp > 0) {
+        // ---- a producer: the early columns of every row, `D` rows ahead ------
+        // Software pipeline over the rows: the loads of a wave's first chunk of
+        // row it + 1 are issued before the sums of its last chunk of row it, the
+        // chain's message a row before it is needed.
+        const int np_ = NG - 1, me = grp - 1;
+        // a column is early when none of the D previous rows holds it (thread l
+        // reads the descriptor entry it wrote itself)
+        auto classify_p = [&](int r_, int buf, int q_) {
+            const int* col_w = col_b + buf * RO;
+            short* em = map_b + buf * pb.rmax;
+            for (int l = tid; l < r_; l += T) {
+                const int j = col_w[l];
+                const int mk = mark_s[j];
+                em[l] = is_late(mk, q_) ? (short)-1 : (short)l;
+                mark_s[j] = (unsigned char)code_of(q_);
+            }
+        };
+        auto first_chunk = [&](const RowX& x, int buf) { // loads of this wave's first chunk of a row
+            const int r_ = x.re - x.rs;
+            const int c = me + np_ * wave;
+            if (wave < SW && c * CW < r_)
+                issue_m(cs_b + buf * RO, map_b + buf * pb.rmax, r_, c, chunk_pieces(cs_b + buf * RO, c), DevScope{}, true);
+        };
+        v4u mpre = { 0u, 0u, 0u, 0u }; // the message asked for a row ahead (wave 0, lane 0)
+#ifdef BXH_PROFILE
+        unsigned long long pacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, pt = wall_clock64();
+#define BXH_PROD_STAMP(slot)                                                   \
+    do {                                                                       \
+        if (tid == 0) {                                                        \
+            const unsigned long long now_ = wall_clock64();                   \
+            pacc[slot] += now_ - pt;                                           \
+            pt = now_;                                                         \
+        }                                                                      \
+    } while (0)
+#else
+#define BXH_PROD_STAMP(slot)                                                   \
+    do {                                                                       \
+    } while (0)
+#endif
+        if (nrows > 0) {
+            classify_p(x0.re - x0.rs, 0, 1);
+            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): see below
+            first_chunk(x0, 0); // (position 1 waits for no row)
+        }
+        for (int it = 0; it < nrows; ++it, x0 = x1, x1 = x2, x2 = x3, k3 = k4) {
+            const int cur = it & 1, q = it + 1;
+            const int rs = x0.rs;
+            const int r = x0.re - x0.rs;
+            const int2* cs_s = cs_b + cur * RO;
+            const int* pe_s = pe_b + cur * RO;
+            const Float* cost_s = cost_b + cur * RO;
+            const short* emap = map_b + cur * pb.rmax;
+            __syncthreads(); // every wave is through with row it - 1 (the other descriptor buffer)
+            BXH_PROD_STAMP(0);
+            if (it + 1 < nrows) {
+                store_desc(x1, cur ^ 1);
+                classify_p(x1.re - x1.rs, cur ^ 1, q + 1);
+                BXH_PROD_STAMP(1);
+                // position q + 1 reads P once the rows up to position q - D are
+                // finished: their pi.  (The columns still being summed for row
+                // it hold none of them.)
+                const int need = q - D;
+                if (tid == 0) {
+                    if (need >= 1)
+                        pi_s[row_at(need - 1)] = poll_pair(mrsrc, (unsigned)(need - 1) * 16u, tag_of(need), mpre);
+                    if (need >= 0 && it + 2 < nrows)
+                        mpre = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, (unsigned)need * 16u, 0, 16);
+                }
+            }
+            BXH_PROD_STAMP(2);
+            __syncthreads(); // the next row's map and descriptor; the message has been seen
+            BXH_PROD_STAMP(3);
+            const int nchunks = (r + CW - 1) / CW;
+            const unsigned roff = (unsigned)(q % PIPE_RING) * (unsigned)pb.rmax * 16u;
+            const unsigned tagq = tag_of(q);
+            if (wave < SW) {
+                int i = wave;
+                int chunk = me + np_ * i;
+                if (chunk >= nchunks && it + 1 < nrows) {
+                    // No chunk of this row: whatever this wave loaded last was
+                    // never staged, and is long here.  Saying so (vmcnt(0)) on
+                    // this path keeps the compiler from waiting, on every
+                    // path, for "pending" loads between the loads it issues
+                    // next, whose registers it reuses for the addresses.
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                    first_chunk(x1, cur ^ 1);
+                }
+                int npm = chunk < nchunks ? chunk_pieces(cs_s, chunk) : 0;
+                while (chunk < nchunks) {
+                    stage_m(emap, r, chunk, npm);
+                    BXH_PROD_STAMP(6);
+                    i += SW;
+                    const int cn = me + np_ * i;
+                    int npn = 0;
+                    if (cn < nchunks) {
+                        npn = chunk_pieces(cs_s, cn);
+                        issue_m(cs_s, emap, r, cn, npn, DevScope{}, true);
+                    } else if (it + 1 < nrows) {
+                        first_chunk(x1, cur ^ 1);
+                    }
+                    BXH_PROD_STAMP(7);
+                    int l;
+                    Float dec;
+                    const Float cst = cost_s[min(chunk * CW + (lane & (CW - 1)), r - 1)];
+                    const Float acc = sum_m(cs_s, pe_s, emap, r, chunk, l, dec, nullptr, true);
+                    const Float spi = __shfl_down(acc, 16); // the pi lane of the same column
+                    if (l >= 0 && (lane & 31) < CW) {
+                        Float v = cst - spi - acc;
+                        if (PM1 && pb.fac_csr[rs + l] < 0)
+                            v = -v;
+                        __builtin_amdgcn_raw_buffer_store_b128(pair_of(v, tagq), xrsrc,
+                                                               roff + (unsigned)l * 16u, 0, 16);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    chunk = cn;
+                    npm = npn;
+                }
+            }
+            BXH_PROD_STAMP(4);
+            if (it + 2 < nrows) {
+                fetch_desc(x2);
+                if (it + 3 < nrows) {
+                    x3 = row_extent(k3);
+                    if (it + 4 < nrows)
+                        k4 = row_at(it + 4);
+                }
+            }
+            BXH_PROD_STAMP(5);
+        }
+#ifdef BXH_PROFILE
+        if (tid == 0 && grp == 1)
+            for (int i = 0; i < 8; ++i)
+                st.prof[(size_t)inst * 32 + 24 + i] += pacc[i];
+#endif
+        return;
+    }
+    // the row chain: which entries of a row are late, and the compact list of
+    // them (its order is free: every column is summed on its own)
+    auto classify_c = [&](int r_, int buf, int q_, int pr_len) { // pr_len: length of the row in front
+        const int* col_w = col_b + buf * RO;
+        const int2* cs_w = cs_b + buf * RO;
+        short* lm = map_b + buf * pb.rmax;
+        short2* lpt = patch_b + buf * pb.rmax;
+        const int* pe_prev = pe_b + (buf ^ 1) * RO; // the row in front of it: the one being updated
+        const int* col_prev = col_b + (buf ^ 1) * RO;
+        unsigned char* lf = flag_b + buf * pb.rmax;
+        int* ln = lnp_b + buf * LNPW;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { // (r <= 2 T: the host checks)
+            const int l = tid + s2 * T;
+            bool late = false;
+            int pcs = 0, ml = -1, ppos = 0;
+            if (l < r_) {
+                const int j = col_w[l];
+                const int mk = mark_s[j];
+                late = is_late(mk, q_);
+                if (q_ >= 2 && mk == code_of(q_ - 1)) { // the previous row holds the column too
+                    ml = markl_s[j];
+                    if (ml >= pr_len || col_prev[ml] != j) // (unless the mark is 255 rows old)
+                        ml = -1;
+                }
+                mark_s[j] = (unsigned char)code_of(q_);
+                markl_s[j] = (unsigned short)l;
+                lf[l] = late ? 1 : 0;
+                const int2 csw = cs_w[l];
+                pcs = (csw.y & 0xffff) >> 4;
+                if (ml >= 0)
+                    ppos = pe_prev[ml] - csw.x;
+            }
+            const unsigned long long bal = __ballot(late);
+            if (bal) { // wave-uniform
+                int base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&misc_s[MS_LCNT + buf], __popcll(bal));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (late) {
+                    const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    lm[pos] = (short)l;
+                    lpt[pos] = make_short2((short)ml, (short)ppos);
+                    atomicMax(&ln[pos >> 4], pcs);
+                }
+            }
+        }
+    };
+    if (PIPE) {
+        for (int i = tid; i < 2 * LNPW; i += T)
+            lnp_b[i] = 0;
+        if (nrows > 0)
+            classify_c(x0.re - x0.rs, 0, 1, 0);
+        __syncthreads();
+    }
+
+    int kprev = 0; // (pipelined sweep: the row whose message is published a row later)
     for (int it = 0; it < nrows; ++it, x0 = x1, x1 = x2, x2 = x3, k3 = k4) {
         const int cur = it & 1;
         const int k = x0.k;
@@ -2650,11 +3149,69 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         const int* oidx_s = oidx_b + cur * RO;
         const short* loc_s = loc_b + cur * pb.rmax;
 
+        // ---- pipelined sweep, row chain: only the late columns are summed
+        // here; the producers' values and the row's own P entries are loaded
+        // meanwhile -----------------------------------------------------------
+        const unsigned char* lflag = flag_b + cur * pb.rmax;
+        Float gP[2] = { 0, 0 };
+        v4u gG[2] = { { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u } };
+        const unsigned roff = (unsigned)((it + 1) % PIPE_RING) * (unsigned)pb.rmax * 16u;
+        if (PIPE) {
+            const short* lmap = map_b + cur * pb.rmax;
+            const int nl = misc_s[MS_LCNT + cur];
+            const int nlc = (nl + CW - 1) / CW;
+            const int* lnp = lnp_b + cur * LNPW;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int l = tid + s2 * T;
+                if (l < r && !lflag[l]) {
+                    gP[s2] = P[pe_s[l]];
+                    gG[s2] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, roff + (unsigned)l * 16u, 0, 16);
+                }
+            }
+            BXH_STAMP(13);
+            if (wave < SW) {
+                // (the wave's first late chunk was loaded during the previous
+                // row, behind its barrier 1; what that row's affect changed
+                // since is patched in the staged copy)
+                const short2* lpatch = patch_b + cur * pb.rmax;
+                int chunk = wave, npm = 0;
+                if (chunk < nlc)
+                    npm = __builtin_amdgcn_readfirstlane(lnp[chunk]);
+                while (chunk < nlc) {
+                    stage_m(lmap, nl, chunk, npm);
+                    const int cn = chunk + SW;
+                    int npn = 0;
+                    if (cn < nlc) {
+                        npn = __builtin_amdgcn_readfirstlane(lnp[cn]);
+                        issue_m(cs_s, lmap, nl, cn, npn, CuScope{});
+                    }
+                    int l;
+                    Float dec = 0;
+                    const Float acc = sum_m(cs_s, pe_s, lmap, nl, chunk, l, dec, lpatch);
+                    const Float spi = __shfl_down(acc, 16); // the pi lane of the same column
+                    if (l >= 0 && (lane & 31) < CW) {
+                        const Float cj = cost_s[l]; // (linear objective: the host checks)
+                        Float v = cj - spi - acc;
+                        if (PM1 && pb.fac_csr[rs + l] < 0)
+                            v = -v;
+                        if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
+                            v += obj_amp * (PM1 ? cj : cost[l]);
+                        val_s[l] = v;
+                        pown_s[l] = dec;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    chunk = cn;
+                    npm = npn;
+                }
+            }
+        }
         // ---- this row's first loads, then the next row's descriptor ---------
         const int nchunks = (ro + CW - 1) / CW;
         int chunk = wave;
         int npm = 0;
-        if (chunk < nchunks) {
+        if (!PIPE && chunk < nchunks) {
             npm = chunk_pieces(cs_s, chunk);
             issue(cs_s, ro, chunk, npm);
         }
@@ -2674,7 +3231,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // by the wave's lanes 32-63 in the same pass as its own chunk -- not
         // in a second pass of its own, which the whole workgroup (and the
         // partners of the instance) would wait for.
-        {
+        if (!PIPE) {
             const bool overflow = pb.spare && nchunks > nwaves; // chunk `nwaves` exists
             auto stage = [&](Float* base_p, unsigned short* base_i, int chunk_, int npm_) {
 #pragma unroll
@@ -2789,7 +3346,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             }
         }
         BXH_STAMP(15);
-        BXH_BARRIER(0);
+        if (!PIPE) // (the chain's late waves write their reduced costs themselves)
+            BXH_BARRIER(0);
         BXH_STAMP(2);
         // Row exchange among the owners: every reduced cost travels as two
         // naturally aligned 8-byte granules {32 value bits, 32-bit tag}, both
@@ -2806,8 +3364,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // this row's stores: their registers were loaded a row ago, so the
         // wait for them returns at once here, while behind the write-through
         // stores it would also wait for the stores' acknowledgements -----------
-        if (it + 1 < nrows)
+        if (it + 1 < nrows) {
             store_desc(x1, cur ^ 1);
+            if (PIPE)
+                classify_c(x1.re - x1.rs, cur ^ 1, it + 2, r);
+        }
         if (tid == 64 % T) { // row constants of select_variables, off thread 0
             misc_s[MS_BMIN] = c_bmin;
             misc_s[MS_BMAX] = c_bmax;
@@ -2823,7 +3384,23 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         }
         BXH_STAMP(11);
 
-        for (int l = tid; l < ro; l += T) {
+        if (PIPE) {
+            const unsigned tagq = tag_of(it + 1);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int l = tid + s2 * T;
+                if (l < r) {
+                    if (!lflag[l]) { // (a late entry: written by the wave that summed it)
+                        Float v = poll_pair(xrsrc, roff + (unsigned)l * 16u, tagq, gG[s2]);
+                        pown_s[l] = gP[s2] * theta;
+                        if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
+                            v += obj_amp * (PM1 ? cost_s[l] : cost[l]);
+                        val_s[l] = v;
+                    }
+                }
+            }
+        }
+        for (int l = tid; !PIPE && l < ro; l += T) {
             const int idx = MW ? oidx_s[l] : l; // position in the whole row
             const int j = col_s[l];
             // (a quadratic objective runs with one owner: x_s is complete)
@@ -2843,8 +3420,22 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             val_s[idx] = v; // own values do not travel
         }
         // the descriptor after the next -> registers, the next row constants
-        // (loads only: nothing here waits)
-        if (it + 2 < nrows) {
+        // (loads only: nothing here waits; the chain issues them behind
+        // barrier 1, after the loads of the next row's late columns)
+        auto prefetch_rows = [&]() {
+            if (it + 2 < nrows) {
+                fetch_desc(x2);
+                if (it + 3 < nrows) {
+                    x3 = row_extent(k3);
+                    if (it + 4 < nrows)
+                        k4 = row_at(it + 4);
+                }
+            }
+            if (it + 1 < nrows)
+                fetch_consts(x1.k);
+        };
+        if (PIPE) {
+        } else if (it + 2 < nrows) {
             fetch_desc(x2);
             if (it + 3 < nrows) {
                 x3 = row_extent(k3);
@@ -2852,7 +3443,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     k4 = row_at(it + 4);
             }
         }
-        if (it + 1 < nrows)
+        if (!PIPE && it + 1 < nrows)
             fetch_consts(x1.k);
         BXH_STAMP(1);
         if (MW) {
@@ -2894,6 +3485,32 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         for (int i = tid; i < 512; i += T)
             reinterpret_cast<uint4*>(htab)[i] = make_uint4(0u, 0u, 0u, 0u);
         BXH_BARRIER(1);
+        if (PIPE) {
+            // this buffer's late list is used up: empty it for the row after the next
+            if (tid < LNPW)
+                lnp_b[cur * LNPW + tid] = 0;
+            if (tid == 0)
+                misc_s[MS_LCNT + cur] = 0;
+            // the next row's late columns: first chunk of every staging wave.
+            // (Nothing is on its way to this wave here: combine has waited for
+            // its loads.  vmcnt(0) tells the compiler, which otherwise waits
+            // between the loads below for loads "pending" from the last row.)
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            if (it + 1 < nrows && wave < SW) {
+                const int nl1 = misc_s[MS_LCNT + (cur ^ 1)];
+                if (wave * CW < nl1)
+                    issue_m(cs_b + (cur ^ 1) * RO, map_b + (cur ^ 1) * pb.rmax, nl1, wave,
+                            __builtin_amdgcn_readfirstlane(lnp_b[(cur ^ 1) * LNPW + wave]), CuScope{});
+            }
+            // every thread has waited for its loads, and with them for the P
+            // entries it stored in the previous row: that row is finished for
+            // the producers
+            if (tid == 0 && it > 0)
+                __builtin_amdgcn_raw_buffer_store_b128(pair_of(pi_s[kprev], tag_of(it)), mrsrc,
+                                                       (unsigned)(it - 1) * 16u, 0, 16);
+            kprev = k;
+            prefetch_rows();
+        }
         if (it + 1 < nrows)
             fill_loc(x1, cur ^ 1);
         BXH_STAMP(3);
@@ -3151,13 +3768,16 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     if (PM1 && pb.fac_csr[rs + idx] < 0)
                         up = !up;
                     const Float p = pown_s[l]; // P[pe] * theta
-                    if (up) {
+                    if (up)
                         atomicOr(&x_s[j >> 5], 1u << (j & 31));
-                        P[pe] = p + d;
-                    } else {
+                    else
                         atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
-                        P[pe] = p - d;
-                    }
+                    if (PIPE) {
+                        const Float np_ = up ? p + d : p - d;
+                        newp_s[l] = np_;
+                        store_p((unsigned)pe, np_);
+                    } else
+                        P[pe] = up ? p + d : p - d;
                 }
                 // R[pos].value after the sort only matters through
                 // stop_iterating: keep its class (N / zero / S)
@@ -3167,6 +3787,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     stale_s[pos] = pos < nN ? repN : (pos < nN + nZ ? (Float)0 : -repN);
                 }
             }
+            BXH_STAMP(12);
             BXH_BARRIER(3);
             BXH_STAMP(6);
             continue;
@@ -3331,13 +3952,16 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 if (PM1 && pb.fac_csr[rs + idx] < 0)
                     up = !up;
                 const Float p = pown_s[l]; // P[pe] * theta
-                if (up) {
+                if (up)
                     atomicOr(&x_s[j >> 5], 1u << (j & 31));
-                    P[pe] = p + d;
-                } else {
+                else
                     atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
-                    P[pe] = p - d;
-                }
+                if (PIPE) {
+                    const Float np_ = up ? p + d : p - d;
+                    newp_s[l] = np_;
+                    store_p((unsigned)pe, np_);
+                } else
+                    P[pe] = up ? p + d : p - d;
             }
         }
         __syncthreads();
@@ -3349,6 +3973,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             pig[i] = pi_s[i];
         for (int i = tid; i <= pb.rmax; i += T)
             staleg[i] = stale_s[i];
+        if ((MW || PIPE) && ord == 7) // pi_sign_change keeps the shuffled R
+            for (int i = tid; i < nrows; i += T)
+                vlist[i] = vrows[i];
     }
     int cnt;
     if (MW) {

@@ -75,7 +75,7 @@ def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweep
     dev.close()
 
 
-@pytest.mark.parametrize("groups", ["1", "2", "4"])
+@pytest.mark.parametrize("groups", ["1", "2", "4", "p2", "p4"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_sweeps_match_oracle(oracle, bxh, case, groups, monkeypatch):
     """Staged kernel, with 1, 2 and 4 cooperating workgroups (column owners)
@@ -95,7 +95,7 @@ def test_sweeps_match_oracle_lane_per_column_kernel(oracle, bxh, case, monkeypat
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
 
 
-@pytest.mark.parametrize("groups", ["1", "4"])
+@pytest.mark.parametrize("groups", ["1", "4", "p4"])
 def test_scpnrh_shaped_rows(oracle, bxh, groups, monkeypatch):
     """Rows of ~500 elements and columns of ~50 (the bench shape, fewer rows):
     several passes per row, more than one piece per column."""
@@ -121,7 +121,7 @@ ORDER_CASES = [
 ]
 
 
-@pytest.mark.parametrize("groups", ["1", "4"])
+@pytest.mark.parametrize("groups", ["1", "4", "p4"])
 @pytest.mark.parametrize("case", ORDER_CASES, ids=[c[0] for c in ORDER_CASES])
 def test_row_orders_match_oracle(oracle, bxh, case, groups, monkeypatch):
     """The sorting orders of compute_order (infeasibility, lagrangian),
@@ -272,7 +272,7 @@ EDGE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("groups", ["1", "4"])
+@pytest.mark.parametrize("groups", ["1", "4", "p4"])
 @pytest.mark.parametrize("case", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
 def test_edge_shapes_match_oracle(oracle, bxh, case, groups, monkeypatch):
     """Ragged rows (down to one element), a variable in no row and one in every

@@ -39,6 +39,11 @@ for step in range(4):
     print(f"step {step}: kernel {ms/n:.2f} ms; ticks/instance {tot:.0f} (= {tot/100e3:.2f} ms @100MHz)")
     for i, nm in enumerate(names):
         print(f"   {nm:12s} {t[:, i].mean() / tot * 100:6.2f} %   {t[:, i].mean() / 100.0 / 1000:8.3f} us/row")
+    if t[:, 24:32].sum() > 0:  # pipelined sweep: the first producer of every instance
+        for i, nm in enumerate(["wait: waves of the previous row", "descriptor + classify", "message poll",
+                                "barrier", "sums + stores (wave 0)", "descriptor prefetch", "wait for loads + staging",
+                                "issue of the next loads"]):
+            print(f"   producer {nm:34s} {t[:, 24 + i].mean() / 100.0 / 1000:8.3f} us/row")
     for i, nm in enumerate(["barrier rc-final", "barrier exchange", "barrier minima", "barrier affect"]):
         print(f"   skew {nm:18s} last-first {t[:, 16 + i].mean() / 100.0 / 1000:6.3f} us/row   "
               f"wave 0 waits {t[:, 20 + i].mean() / 100.0 / 1000:6.3f} us/row")
