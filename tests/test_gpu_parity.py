@@ -284,6 +284,25 @@ def test_edge_shapes_match_oracle(oracle, bxh, case, groups, monkeypatch):
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p, sweeps=8, push_at=(3, 6))
 
 
+@pytest.mark.parametrize("lookahead", ["2", "3"])
+def test_pipelined_sweep_mark_wrap_and_lookahead(oracle, bxh, lookahead, monkeypatch):
+    """Pipelined sweep (row chain + producers): more than 255 rows per sweep, so
+    that the one-byte column marks come round (a column last seen 255 rows
+    earlier is then summed by the chain although no recent row holds it:
+    both sides must take the same decision), with both look-ahead depths; a
+    wide instance where most columns are early and a narrow one where nearly
+    every column is late."""
+    monkeypatch.delenv("BXH_FORCE_V1", raising=False)
+    monkeypatch.setenv("BXH_GROUPS", "p4")
+    monkeypatch.setenv("BXH_LOOKAHEAD", lookahead)
+    inst = synth.make_scp(600, 3000, 0.01, "int", 91)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=5, push_at=(3,))
+    inst = synth.make_scp(520, 60, 0.3, "real", 92)
+    run_case(oracle, bxh, inst, 1, False, 1, 0.2, batch=2, sweeps=5, push_at=(2,))
+    inst = synth.make_pm1(300, 900, 0.02, "int", 93)
+    run_case(oracle, bxh, inst, 0, True, 2, 0.1, batch=2, sweeps=5, push_at=(4,))
+
+
 def test_invalid_inputs_are_refused(bxh):
     """bxh_create validates what the Solver constructors assume."""
     inst = synth.make_scp(10, 30, 0.2, "int", 73)
