@@ -3081,22 +3081,43 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     }
     // the row chain: which entries of a row are late, and the compact list of
     // them (its order is free: every column is summed on its own)
-    auto classify_c = [&](int r_, int buf, int q_, int pr_len) { // pr_len: length of the row in front
-        const int* col_w = col_b + buf * RO;
-        const int2* cs_w = cs_b + buf * RO;
+    // `base`, `stride`: the threads that take part and the entries they take
+    // (whole waves).  `rs_` >= 0: the descriptor of the row comes straight from
+    // global memory (the chain's non-staging waves write the next row's
+    // descriptor and classify it while the staging waves sum the late columns).
+    auto classify_c = [&](int r_, int buf, int q_, int pr_len, int base, int stride, int rs_) {
+        int* col_w = col_b + buf * RO;
+        int2* cs_w = cs_b + buf * RO;
+        int* pe_w = pe_b + buf * RO;
+        Float* cost_w = cost_b + buf * RO;
         short* lm = map_b + buf * pb.rmax;
         short2* lpt = patch_b + buf * pb.rmax;
         const int* pe_prev = pe_b + (buf ^ 1) * RO; // the row in front of it: the one being updated
         const int* col_prev = col_b + (buf ^ 1) * RO;
         unsigned char* lf = flag_b + buf * pb.rmax;
         int* ln = lnp_b + buf * LNPW;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) { // (r <= 2 T: the host checks)
-            const int l = tid + s2 * T;
+        const int trips = (r_ + stride - 1) / stride;
+        for (int s2 = 0; s2 < trips; ++s2) { // (wave-uniform)
+            const int l = base + s2 * stride;
             bool late = false;
             int pcs = 0, ml = -1, ppos = 0;
             if (l < r_) {
-                const int j = col_w[l];
+                int j;
+                int2 csw;
+                if (rs_ >= 0) {
+                    const int e = rs_ + l;
+                    csw = pb.row_cs[e];
+                    const int pe_ = pb.row_pos[e];
+                    j = pb.row_col[e];
+                    const Float cst = ((const Float*)pb.desc_cost)[e];
+                    cs_w[l] = csw;
+                    pe_w[l] = pe_;
+                    col_w[l] = j;
+                    cost_w[l] = cst;
+                } else {
+                    j = col_w[l];
+                    csw = cs_w[l];
+                }
                 const int mk = mark_s[j];
                 late = is_late(mk, q_);
                 if (q_ >= 2 && mk == code_of(q_ - 1)) { // the previous row holds the column too
@@ -3107,19 +3128,18 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 mark_s[j] = (unsigned char)code_of(q_);
                 markl_s[j] = (unsigned short)l;
                 lf[l] = late ? 1 : 0;
-                const int2 csw = cs_w[l];
                 pcs = (csw.y & 0xffff) >> 4;
                 if (ml >= 0)
                     ppos = pe_prev[ml] - csw.x;
             }
             const unsigned long long bal = __ballot(late);
             if (bal) { // wave-uniform
-                int base = 0;
+                int pbase = 0;
                 if (lane == 0)
-                    base = atomicAdd(&misc_s[MS_LCNT + buf], __popcll(bal));
-                base = __builtin_amdgcn_readfirstlane(base);
+                    pbase = atomicAdd(&misc_s[MS_LCNT + buf], __popcll(bal));
+                pbase = __builtin_amdgcn_readfirstlane(pbase);
                 if (late) {
-                    const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    const int pos = pbase + __popcll(bal & ((1ull << lane) - 1ull));
                     lm[pos] = (short)l;
                     lpt[pos] = make_short2((short)ml, (short)ppos);
                     atomicMax(&ln[pos >> 4], pcs);
@@ -3131,7 +3151,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         for (int i = tid; i < 2 * LNPW; i += T)
             lnp_b[i] = 0;
         if (nrows > 0)
-            classify_c(x0.re - x0.rs, 0, 1, 0);
+            classify_c(x0.re - x0.rs, 0, 1, 0, tid, T, -1);
         __syncthreads();
     }
 
@@ -3170,6 +3190,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
             }
             BXH_STAMP(13);
+            if (wave >= SW && it + 1 < nrows)
+                classify_c(x1.re - x1.rs, cur ^ 1, it + 2, r, tid - SW * 64, T - SW * 64, x1.rs);
             if (wave < SW) {
                 // (the wave's first late chunk was loaded during the previous
                 // row, behind its barrier 1; what that row's affect changed
@@ -3364,11 +3386,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // this row's stores: their registers were loaded a row ago, so the
         // wait for them returns at once here, while behind the write-through
         // stores it would also wait for the stores' acknowledgements -----------
-        if (it + 1 < nrows) {
+        if (!PIPE && it + 1 < nrows)
             store_desc(x1, cur ^ 1);
-            if (PIPE)
-                classify_c(x1.re - x1.rs, cur ^ 1, it + 2, r);
-        }
         if (tid == 64 % T) { // row constants of select_variables, off thread 0
             misc_s[MS_BMIN] = c_bmin;
             misc_s[MS_BMAX] = c_bmax;
@@ -3422,9 +3441,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // the descriptor after the next -> registers, the next row constants
         // (loads only: nothing here waits; the chain issues them behind
         // barrier 1, after the loads of the next row's late columns)
-        auto prefetch_rows = [&]() {
+        auto prefetch_rows = [&]() { // (the chain's descriptors do not travel through registers)
             if (it + 2 < nrows) {
-                fetch_desc(x2);
                 if (it + 3 < nrows) {
                     x3 = row_extent(k3);
                     if (it + 4 < nrows)
