@@ -3077,6 +3077,22 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             for (int i = 0; i < 8; ++i)
                 st.prof[(size_t)inst * 32 + 24 + i] += pacc[i];
 #endif
+        // compute_violated_constraints of the new x: a share of the rows (the
+        // chain publishes x, every workgroup flags its rows, the chain compacts)
+        if (tid == 0)
+            wait_arrivals(cnt_row, 1u, err_word);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        unsigned* xp = (unsigned*)(smem + lp.off_union); // (the staging slots are free now)
+        for (int i = tid; i < 2 * pb.nwords; i += T)
+            xp[i] = xg[i];
+        __syncthreads();
+        flag_violated(pb, xp, st.vflag + (size_t)inst * pb.m, (int)((long long)pb.m * grp / NG),
+                      (int)((long long)pb.m * (grp + 1) / NG));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_fetch_add(cnt_end, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     // the row chain: which entries of a row are late, and the compact list of
@@ -4016,6 +4032,20 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                                       st.vflag + ((size_t)inst * NG + grp) * pb.m,
                                       grp == 0 ? out_list : vrows,
                                       misc_s + MS_WAVES);
+    } else if (PIPE) {
+        for (int i = tid; i < 2 * pb.nwords; i += T)
+            xg[i] = x_s[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) // x is there: the producers flag their shares of the rows
+            __hip_atomic_store(cnt_row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        signed char* vf = st.vflag + (size_t)inst * pb.m;
+        flag_violated(pb, x_s, vf, 0, (int)((long long)pb.m / NG));
+        if (tid == 0)
+            wait_arrivals(cnt_end, (unsigned)(NG - 1), err_word);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        cnt = rebuild_violated(pb, x_s, vf, out_list, misc_s + MS_WAVES, true);
     } else {
         for (int i = tid; i < 2 * pb.nwords; i += T)
             xg[i] = x_s[i];
