@@ -30,7 +30,7 @@ BXH_ERR_DEVICE = -4
 # every symbol include/bxh.h declares (tests check the library exports them)
 SYMBOLS = [
     "bxh_last_error", "bxh_create", "bxh_destroy", "bxh_set_stream", "bxh_batch",
-    "bxh_nwords", "bxh_rmax", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_set_pi", "bxh_get_pi",
+    "bxh_nwords", "bxh_rmax", "bxh_kernel_form", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_set_pi", "bxh_get_pi",
     "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset", "bxh_reset_all",
     "bxh_order_create", "bxh_order_init", "bxh_order_init_masked", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
     "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time",
@@ -131,7 +131,7 @@ def lib():
         ]
         L.bxh_destroy.argtypes = [C.c_void_p]
         L.bxh_set_stream.argtypes = [C.c_void_p, C.c_void_p]
-        for nm in ("bxh_batch", "bxh_nwords", "bxh_rmax"):
+        for nm in ("bxh_batch", "bxh_nwords", "bxh_rmax", "bxh_kernel_form"):
             getattr(L, nm).argtypes = [C.c_void_p]
         L.bxh_set_x.argtypes = [C.c_void_p, C.c_int, u64p]
         L.bxh_get_x.argtypes = [C.c_void_p, C.c_int, u64p]
@@ -213,6 +213,7 @@ class DeviceBatch:
         self.h = h
         self.nwords = self.L.bxh_nwords(self.h)
         self.rmax = self.L.bxh_rmax(self.h)
+        self.kernel_form = self.L.bxh_kernel_form(self.h)
         self._status = np.zeros(self.batch, STATUS_DTYPE)
 
     def close(self):

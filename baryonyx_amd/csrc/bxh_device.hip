@@ -1183,6 +1183,20 @@ bxh_rmax(bxh_handle h)
 }
 
 int
+bxh_kernel_form(bxh_handle h)
+{
+    if (!h)
+        return BXH_ERR_INVALID;
+    if (h->version == 3)
+        return 3;
+    if (h->version != 2)
+        return 1;
+    if (h->pipe)
+        return 40 + h->pipe;
+    return h->groups > 1 ? 20 + h->groups : 2;
+}
+
+int
 bxh_set_x(bxh_handle h, int inst, const uint64_t* words)
 {
     if (int rc = check_inst(h, inst))

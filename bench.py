@@ -145,6 +145,22 @@ def cpu_baseline(inst, params, float_type, seconds, threads):
     }
 
 
+def kernel_label(form):
+    """bxh_kernel_form -> the kernel the roofline line is about."""
+    if form == 1:
+        return "bxh::sweep_kernel (lane per column, 1 workgroup / instance)"
+    if form == 2:
+        return "bxh::sweep_kernel_v2 (staged, 1 workgroup / instance)"
+    if form == 3:
+        return "bxh::sweep_kernel_z"
+    if 20 < form < 40:
+        return f"bxh::sweep_kernel_v2 (staged, {form - 20} lock-step column owners / instance)"
+    if form > 40:
+        return (f"bxh::sweep_kernel_v2 (pipelined sweep: 1 row chain + {form - 41} producer "
+                "workgroups / instance)")
+    return "bxh::sweep_kernel"
+
+
 def pmc_traffic(workload, float_type):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this very
     workload (profiles/r*/pmc_traffic.json, made by tools/pmc_traffic.py); the
@@ -302,7 +318,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(workload, float_type),
-                "kernel": "bxh::sweep_kernel",
+                "kernel": kernel_label(dev.kernel_form),
                 "launches": int(launches),
                 "avg_launch_ms": kernel_ms / max(launches, 1),
                 "alg_bytes_per_row_update": mean_row_bytes,

@@ -142,6 +142,14 @@ int bxh_set_stream(bxh_handle h, void* hip_stream);
 int bxh_batch(bxh_handle h);
 int bxh_nwords(bxh_handle h); /* bit_array block count n/64 + 1, bit-array.hpp:60-66 */
 int bxh_rmax(bxh_handle h);
+/* Which form of the row-update kernel bxh_create chose for this handle
+ * (diagnostics and bench labels; the results do not depend on it):
+ *   1  lane-per-column walk, one workgroup per instance
+ *   2  staged pipeline, one workgroup per instance
+ *   3  inequalities-Z kernel
+ *   20 + g  staged pipeline, g lock-step column owners per instance
+ *   40 + w  pipelined sweep, w workgroups per instance (1 row chain + w - 1 producers) */
+int bxh_kernel_form(bxh_handle h);
 
 /* Solver fields x / pi / P (P in CSR element order, as `slv.P[e]`), and the
  * worker's random engine. `inst` in [0, batch). */

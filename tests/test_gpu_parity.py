@@ -29,7 +29,8 @@ CASES = [
 ]
 
 
-def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweeps=12, push_at=(5, 9)):
+def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweeps=12, push_at=(5, 9),
+             expect_form=None):
     theta = 0.5
     orcs = []
     for b in range(batch):
@@ -41,6 +42,8 @@ def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweep
     dev = bxh.DeviceBatch(inst, cost, batch, float_type=float_type, maximize=maximize,
                           qcost=orcs[0].qcost())
     assert dev.rmax == orcs[0].rmax
+    if expect_form is not None:
+        assert dev.kernel_form == expect_form, dev.kernel_form
 
     for b, s in enumerate(orcs):
         x0 = random_x(inst.n, x0p, 77 + b) if x0p > 0 else np.zeros(s.nwords, np.uint64)
@@ -296,7 +299,7 @@ def test_pipelined_sweep_mark_wrap_and_lookahead(oracle, bxh, lookahead, monkeyp
     monkeypatch.setenv("BXH_GROUPS", "p4")
     monkeypatch.setenv("BXH_LOOKAHEAD", lookahead)
     inst = synth.make_scp(600, 3000, 0.01, "int", 91)
-    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=5, push_at=(3,))
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=5, push_at=(3,), expect_form=44)
     inst = synth.make_scp(520, 60, 0.3, "real", 92)
     run_case(oracle, bxh, inst, 1, False, 1, 0.2, batch=2, sweeps=5, push_at=(2,))
     inst = synth.make_pm1(300, 900, 0.02, "int", 93)
