@@ -3518,6 +3518,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // slots: clear
         for (int i = tid; i < 512; i += T)
             reinterpret_cast<uint4*>(htab)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (PIPE) // what this thread stored to P in the previous row has arrived (a thread
+            __builtin_amdgcn_s_waitcnt(0x0f70); // without a load of its own would not wait)
         BXH_BARRIER(1);
         if (PIPE) {
             // this buffer's late list is used up: empty it for the row after the next
