@@ -2901,17 +2901,26 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             }
             const Float2* sp2 = reinterpret_cast<const Float2*>(wst_p + u * SP);
             const uint2* si2 = reinterpret_cast<const uint2*>(wst_i + u * SI);
-            for (int i0 = 0; i0 < cpad; i0 += 16) {
-                Float v[16];
-                unsigned sg[8]; // 16 packed 16-bit indices
+            // the row indices travel one batch of 16 ahead of the entries: the
+            // pi lanes then wait for one LDS round trip per batch, not two
+            unsigned sgn[8]; // 16 packed 16-bit indices of the next batch
+            auto read_idx = [&](int i0_) {
                 if (is_pi || PM1) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const uint2 w = si2[(i0 >> 2) + b];
-                        sg[2 * b] = w.x;
-                        sg[2 * b + 1] = w.y;
+                        const uint2 w = si2[(i0_ >> 2) + b];
+                        sgn[2 * b] = w.x;
+                        sgn[2 * b + 1] = w.y;
                     }
                 }
+            };
+            read_idx(0);
+            for (int i0 = 0; i0 < cpad; i0 += 16) {
+                Float v[16];
+                unsigned sg[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    sg[b] = sgn[b];
                 if (is_pi) {
 #pragma unroll
                     for (int b = 0; b < 8; ++b) {
@@ -2926,6 +2935,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         v[2 * b + 1] = w.y;
                     }
                 }
+                if (i0 + 16 < cpad)
+                    read_idx(i0 + 16);
 #pragma unroll
                 for (int b = 0; b < 16; ++b) {
                     Float term = v[b];
