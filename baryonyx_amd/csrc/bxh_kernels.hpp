@@ -2518,7 +2518,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     MinStd rng;
     rng.s = st.status[inst].rng; // meaningful in thread 0 only
     const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
-    double alg_bytes = 0.0; // thread 0 only
+    double alg_bytes = 0.0; // thread t0 only
 
     if (MW || PIPE) {
         for (int i = tid; i < nrows; i += T)
@@ -2541,6 +2541,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     rng.s = (unsigned)misc_s[MS_RNG];
 
     const int l8 = tid & 7;
+    // The duties of a single thread (row constants, pi_k and d of a row, the
+    // serial part of a tied row, the status block): in the pipelined chain on
+    // the non-staging waves -- the staging waves are the critical path.
+    const int t0 = (PIPE && grp == 0) ? SW * 64 : 0;
+    const int t1 = (PIPE && grp == 0) ? (SW * 64 + 64) % T : 64 % T;
     Prof prof;
 #ifdef BXH_PROFILE
     unsigned long long skew[4] = { 0, 0, 0, 0 }, own[4] = { 0, 0, 0, 0 };
@@ -2659,7 +2664,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     int c_bmin = 0, c_bmax = 0, c_bneg = 0;
     double c_rbytes = 0.0;
     auto fetch_consts = [&](int k_) {
-        if (tid == 64 % T) {
+        if (tid == t1) {
             c_bmin = pb.bmin[k_];
             c_bmax = pb.bmax[k_];
             c_bneg = pb.bneg[k_];
@@ -3415,7 +3420,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // stores it would also wait for the stores' acknowledgements -----------
         if (!PIPE && it + 1 < nrows)
             store_desc(x1, cur ^ 1);
-        if (tid == 64 % T) { // row constants of select_variables, off thread 0
+        if (tid == t1) { // row constants of select_variables, off thread 0
             misc_s[MS_BMIN] = c_bmin;
             misc_s[MS_BMAX] = c_bmax;
             misc_s[MS_BNEG] = c_bneg;
@@ -3521,7 +3526,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             }
         }
         const int n2 = next_pow2(r < 2 ? 2 : r);
-        if (tid == 0) {
+        if (tid == t0) {
             misc_s[MS_TIE] = 0;
             misc_s[MS_FAST] = 0;
         }
@@ -3536,7 +3541,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             // this buffer's late list is used up: empty it for the row after the next
             if (tid < LNPW)
                 lnp_b[cur * LNPW + tid] = 0;
-            if (tid == 0)
+            if (tid == t0)
                 misc_s[MS_LCNT + cur] = 0;
             // the next row's late columns: first chunk of every staging wave.
             // (Nothing is on its way to this wave here: combine has waited for
@@ -3552,7 +3557,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             // every thread has waited for its loads, and with them for the P
             // entries it stored in the previous row: that row is finished for
             // the producers
-            if (tid == 0 && it > 0)
+            if (tid == SW * 64 && it > 0) // (a wave without loads to issue here)
                 __builtin_amdgcn_raw_buffer_store_b128(pair_of(pi_s[kprev], tag_of(it)), mrsrc,
                                                        (unsigned)(it - 1) * 16u, 0, 16);
             kprev = k;
@@ -3794,7 +3799,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             const unsigned long long thr = f_thr;
             const Float d = f_d;
             const int nN = f_nN, nZ = f_nZ;
-            if (tid == 0) {
+            if (tid == t0) {
                 alg_bytes += *(const double*)(misc_s + MS_RBYTES);
                 if (mode == 2) {
                     pi_s[k] = f_newpi;
@@ -3877,7 +3882,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         }
 
         // ---- thread 0: tie shuffle, select_variables, pi and d of affect ---
-        if (tid == 0) {
+        if (tid == t0) {
             alg_bytes += *(const double*)(misc_s + MS_RBYTES);
             if (misc_s[MS_TIE] && !shuffled) {
                 int b0 = 0;
@@ -4077,7 +4082,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     }
 #endif
 
-    if (tid == 0 && grp == 0) {
+    if (tid == t0 && grp == 0) {
         if (!keep)
             st.vcount[inst] = cnt;
         DevStatus s = st.status[inst];
