@@ -1076,6 +1076,9 @@ bxh_create(const bxh_problem* pb,
     dp.lookahead = h->lookahead;
     dp.sw_chain = h->sw_chain;
     dp.sw_prod = h->sw_prod;
+    dp.gather_other = 256;
+    if (const char* eo = std::getenv("BXH_PIPE_GATHER"))
+        dp.gather_other = std::max(0, std::atoi(eo));
     dp.sub_ptr = h->sub_ptr.p;
     dp.sub_e = h->sub_e.p;
     dp.sub_desc = h->sub_desc.p;

@@ -33,6 +33,7 @@ struct DevProblem
     int pipe;     // pipelined sweep: workgroups per instance (1 row chain + producers), 0 = off
     int lookahead; // pipelined sweep: a producer works on the row D positions past the last finished one
     int sw_chain, sw_prod; // pipelined sweep: waves with staging slots in the chain / a producer
+    int gather_other; // pipelined sweep: entries of a row whose values the chain's non-staging waves fetch
     int cmax;     // longest column (real entries)
     int kind;     // bxh_kind
     int maximize; // 0 / 1
@@ -3205,6 +3206,22 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // here; the producers' values and the row's own P entries are loaded
         // meanwhile -----------------------------------------------------------
         const unsigned char* lflag = flag_b + cur * pb.rmax;
+        // whose entries a thread fetches (the producers' value, the own P entry)
+        // and turns into val_s: the non-staging waves take the first `go`
+        // entries of the row, two each at most, the staging waves -- busy with
+        // the late columns -- the rest
+        int gl[2] = { tid, tid + T };
+        if (PIPE) {
+            const int STG = SW * 64, OTH = T - STG;
+            const int go = min(pb.gather_other, 2 * OTH);
+            if (wave >= SW) {
+                gl[0] = tid - STG;
+                gl[1] = OTH + tid - STG < go ? OTH + tid - STG : 0x7fffffff;
+            } else {
+                gl[0] = go + tid;
+                gl[1] = go + STG + tid;
+            }
+        }
         Float gP[2] = { 0, 0 };
         v4u gG[2] = { { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u } };
         const unsigned roff = (unsigned)((it + 1) % PIPE_RING) * (unsigned)pb.rmax * 16u;
@@ -3215,7 +3232,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             const int* lnp = lnp_b + cur * LNPW;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int l = tid + s2 * T;
+                const int l = gl[s2];
                 if (l < r && !lflag[l]) {
                     gP[s2] = P[pe_s[l]];
                     gG[s2] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, roff + (unsigned)l * 16u, 0, 16);
@@ -3439,7 +3456,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             const unsigned tagq = tag_of(it + 1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int l = tid + s2 * T;
+                const int l = gl[s2];
                 if (l < r) {
                     if (!lflag[l]) { // (a late entry: written by the wave that summed it)
                         Float v = poll_pair(xrsrc, roff + (unsigned)l * 16u, tagq, gG[s2]);
