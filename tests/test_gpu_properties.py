@@ -66,6 +66,44 @@ def test_full_size_batch_properties(bxh, oracle, float_type):
     dev.close()
 
 
+@pytest.mark.parametrize("float_type", [1, 0], ids=["f64", "f32"])
+def test_full_size_restart_sweeps_match_oracle(bxh, oracle, float_type):
+    """The bench step at the bench size (64 instances, the pipelined sweep: one
+    row chain + 3 producer workgroups per instance): three restart-sweeps, two
+    instances replayed by the oracle, bit for bit."""
+    inst = synth.config_c2("int")
+    B = 64
+    cost = normalize_costs(inst.dense_costs(), 4, float_type)
+    delta = compute_delta(cost, 0.5, float_type)
+    dev = bxh.DeviceBatch(inst, cost, B, float_type=float_type)
+    assert dev.kernel_form == 44, dev.kernel_form
+    watch = (0, 63)
+    orcs = {}
+    for b in range(B):
+        dev.set_rng(b, 2000 + b)
+    for b in watch:
+        orcs[b] = oracle.Solver(inst, float_type=float_type, sort_mode=1, cost_norm=4, seed=2000 + b)
+    kappa = np.linspace(0.0, 0.2, B)
+    x0 = np.zeros((B, dev.nwords), np.uint64)
+    for it in range(3):
+        dev.set_x_all(x0)
+        dev.order_init(0)
+        st = dev.sweep(kappa, delta, 0.5)
+        for b in watch:
+            o = orcs[b]
+            o.set_x(x0[b])
+            o.order_init(0)
+            r = o.sweep(float(kappa[b]), delta, 0.5)
+            tag = f"restart {it} inst {b}"
+            assert r == st["remaining"][b], tag
+            assert np.array_equal(o.get_x(), dev.get_x(b)), tag + " x"
+            assert bits_equal(o.get_pi(), dev.get_pi(b)), tag + " pi"
+            assert bits_equal(o.get_P(), dev.get_P(b)), tag + " P"
+            assert o.rng == st["rng"][b], tag + " rng"
+        kappa = kappa + 0.05
+    dev.close()
+
+
 def test_restart_from_bastert_point(bxh):
     """x <- 0 + order_init restores the full violated list; P and pi persist."""
     inst = synth.make_scp(200, 2000, 0.05, "real", 9)
