@@ -6,6 +6,7 @@
 // HIP cannot run them they return BXH_ERR_DEVICE.
 #include "../../include/bxh.h"
 #include "bxh_kernels.hpp"
+#include "bxh_wide.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -84,6 +85,7 @@ struct bxh_handle_s
     int lookahead = 2;         // v2: rows between a producer and the last finished row
     int sw_chain = 0, sw_prod = 0; // v2: staging waves of the chain / a producer
     int romax = 0;             // longest per-owner part of a row
+    int wide_g = 0;            // wide kernel (version 4): workgroups per instance
     unsigned epoch = 0;        // sweep launches so far (tags of the row exchange)
 
     hipStream_t own_stream = nullptr;
@@ -134,6 +136,13 @@ struct bxh_handle_s
     DevBuf<unsigned long long> prof;
     DevBuf<double> kappa;
     DevBuf<unsigned char> active;
+    // wide kernel (bxh_wide.hpp)
+    DevBuf<int2> col_desc;
+    DevBuf<unsigned char> piw;
+    DevBuf<unsigned long long> whash, wrec, vbuf, bkey;
+    DevBuf<unsigned> wcnt;
+    DevBuf<int> bid, vflag32;
+    bxh::WideParams wp{};
 
     // HIP events around every sweep kernel launch (bxh_kernel_time)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -289,6 +298,13 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
 #undef BXH_V2
     } else if (h->version == 3) {
         BXH_LAUNCH((bxh::sweep_kernel_z<Float>));
+    } else if (h->version == 4) {
+        if (pm1)
+            hipLaunchKernelGGL((bxh::sweep_kernel_wide<Float, true>), dim3(h->batch * h->wide_g),
+                               dim3(bxh::WIDE_T), h->lds_bytes, h->stream, h->dp, h->ds, a, h->wp);
+        else
+            hipLaunchKernelGGL((bxh::sweep_kernel_wide<Float, false>), dim3(h->batch * h->wide_g),
+                               dim3(bxh::WIDE_T), h->lds_bytes, h->stream, h->dp, h->ds, a, h->wp);
     } else {
         if (pm1)
             BXH_LAUNCH((bxh::sweep_kernel<Float, true>));
@@ -404,7 +420,30 @@ bxh_create(const bxh_problem* pb,
     // of them must be resident together, one per CU ----------------------
     const char* force_v1 = std::getenv("BXH_FORCE_V1");
     const bool zsolver = kind == BXH_INEQ_Z;
-    const bool v2_ok = !zsolver && cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
+    // The wide kernel (bxh_wide.hpp) takes what the staged kernel cannot:
+    // columns of more than 128 entries, m >= 32768 (pi beyond LDS); linear
+    // objective, 01 / 101 solvers.  BXH_GROUPS=w<G> forces it (tests).
+    int wide_g = 0;
+    {
+        const char* eg = std::getenv("BXH_GROUPS");
+        const bool asked = eg && eg[0] == 'w';
+        const bool fits_v2 = cmax <= 128 && m < 32768;
+        if (!zsolver && pb->n_quad == 0 && (asked || (!fits_v2 && !(force_v1 && force_v1[0] == '1')))) {
+            int cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+            // every workgroup should get a tile (32 columns) per wave of the longest row
+            wide_g = std::max(1, std::min(cus / batch, rmax / 256));
+            if (asked && std::atoi(eg + 1) > 0)
+                wide_g = std::atoi(eg + 1);
+            if (batch * wide_g > cus || wide_g > 64)
+                return fail(BXH_ERR_UNSUPPORTED,
+                            "the cooperating workgroups of all instances must be resident "
+                            "together (batch * workgroups per instance <= CUs)");
+        }
+    }
+    const bool v2_ok = !wide_g && !zsolver && cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
     int groups = 1;
     if (v2_ok) {
         int cus = 256;
@@ -697,7 +736,7 @@ bxh_create(const bxh_problem* pb,
     const int lds_limit = 160 * 1024;
     const bxh::LdsPlan lp =
       bxh::lds_plan(m, h->nwords, rmax, static_cast<int>(h->fsize));
-    if (lp.total > lds_limit)
+    if (lp.total > lds_limit && !wide_g)
         return fail(BXH_ERR_UNSUPPORTED,
                     "instance does not fit the one-workgroup-per-instance "
                     "kernel (pi, x and the row buffers must fit 160 KiB of "
@@ -820,6 +859,19 @@ bxh_create(const bxh_problem* pb,
                 }
             }
     }
+    int wide_chmax = 0;
+    if (wide_g) {
+        wide_chmax = (((rmax + wide_g - 1) / wide_g) + bxh::WIDE_TILE - 1) & ~(bxh::WIDE_TILE - 1);
+        const bxh::WideLds wl = bxh::wide_lds(wide_g, wide_chmax, static_cast<int>(h->fsize));
+        if (wl.total > lds_limit)
+            return fail(BXH_ERR_UNSUPPORTED,
+                        "rows too long for the workgroups this batch leaves to an instance");
+        h->version = 4;
+        h->wide_g = wide_g;
+        h->threads = bxh::WIDE_T;
+        h->lds_bytes = static_cast<size_t>(wl.total);
+        h->lds_bytes_init = 0;
+    }
     if (std::getenv("BXH_DEBUG"))
         std::fprintf(stderr, "bxh: kernel v%d threads=%d lds=%zu np=%d groups=%d pipe=%d (chain %d, producer %d staging waves, lookahead %d)\n",
                      h->version, h->threads, h->lds_bytes, h->nb, groups, h->pipe, h->sw_chain,
@@ -921,7 +973,7 @@ bxh_create(const bxh_problem* pb,
 
     const size_t B = static_cast<size_t>(batch);
     const size_t GG = static_cast<size_t>(groups);
-    const size_t WG = static_cast<size_t>(h->pipe ? h->pipe : groups); // workgroups per instance
+    const size_t WG = static_cast<size_t>(wide_g ? wide_g : (h->pipe ? h->pipe : groups)); // workgroups per instance
     HIP_TRY(h->P.alloc(B * GG * nnzp * h->fsize));
     const size_t LC = static_cast<size_t>(std::max(m, n));
     h->lcap = static_cast<int>(LC);
@@ -994,8 +1046,53 @@ bxh_create(const bxh_problem* pb,
                           hipMemcpyHostToDevice));
     }
 
+    if (wide_g) {
+        std::vector<int2> cd(static_cast<size_t>(n));
+        for (int j = 0; j != n; ++j)
+            cd[j] = make_int2(col_start[j], std::max(16, (col_len[j] + 15) & ~15));
+        HIP_TRY(h->col_desc.upload(cd));
+        const size_t Gz = static_cast<size_t>(wide_g);
+        size_t hs = 1024;
+        while (hs < 4 * static_cast<size_t>(rmax))
+            hs <<= 1;
+        const size_t n2big = rmax > bxh::WIDE_SMALL ? static_cast<size_t>(bxh::next_pow2(rmax)) : 0;
+        HIP_TRY(h->piw.alloc(B * Gz * (static_cast<size_t>(m) + 1) * h->fsize));
+        HIP_TRY(h->whash.alloc(B * hs));
+        HIP_TRY(hipMemset(h->whash.p, 0, B * hs * sizeof(unsigned long long)));
+        HIP_TRY(h->wrec.alloc(B * Gz * 8));
+        HIP_TRY(h->wcnt.alloc(4 * B + 1));
+        HIP_TRY(hipMemset(h->wcnt.p, 0, (4 * B + 1) * sizeof(unsigned)));
+        HIP_TRY(h->vbuf.alloc(B * static_cast<size_t>(rmax)));
+        HIP_TRY(h->bkey.alloc(B * Gz * n2big));
+        HIP_TRY(h->bid.alloc(B * Gz * n2big));
+        HIP_TRY(h->vflag32.alloc(B * static_cast<size_t>(m)));
+        bxh::WideParams& wp = h->wp;
+        wp.G = wide_g;
+        wp.chmax = wide_chmax;
+        wp.hmask = static_cast<unsigned>(hs - 1);
+        wp.n2big = static_cast<int>(n2big);
+        wp.col_desc = h->col_desc.p;
+        wp.piw = h->piw.p;
+        wp.whash = h->whash.p;
+        wp.wrec = h->wrec.p;
+        wp.wcnt = h->wcnt.p;
+        wp.vbuf = h->vbuf.p;
+        wp.bkey = h->bkey.p;
+        wp.bid = h->bid.p;
+        wp.vflag32 = h->vflag32.p;
+        const int wl = static_cast<int>(h->lds_bytes);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    }
+
     // the kernels may ask for more than the 64 KiB default dynamic LDS
-    {
+    if (!wide_g) {
         const int want = static_cast<int>(std::max(h->lds_bytes, h->lds_bytes_init));
 #define BXH_SET_LDS(K)                                                         \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&K),             \
@@ -1192,6 +1289,8 @@ bxh_kernel_form(bxh_handle h)
         return BXH_ERR_INVALID;
     if (h->version == 3)
         return 3;
+    if (h->version == 4)
+        return 100 + h->wide_g;
     if (h->version != 2)
         return 1;
     if (h->pipe)
@@ -1347,6 +1446,10 @@ bxh_order_create(bxh_handle h, int order)
         return fail(BXH_ERR_UNSUPPORTED,
                     "pi_sign_change walks row ids 0..n-1 (itm-common.hpp:672-674): "
                     "needs n <= m");
+    if (h->version == 4 && order > BXH_ORDER_RANDOM_SORTING)
+        return fail(BXH_ERR_UNSUPPORTED,
+                    "the wide kernel walks the rows in the orders none / reversing / "
+                    "random_sorting only");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->policy = order;
@@ -1379,6 +1482,26 @@ bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* r
         HIP_TRY(hipMemcpyAsync(h->active.p, h->h_active, static_cast<size_t>(h->batch),
                                hipMemcpyHostToDevice, h->stream));
         dev_active = h->active.p;
+    }
+    if (h->version == 4) { // x, pi beyond LDS: flags from global memory, then the compaction
+        int parts = 1;
+        while (h->batch * parts * 2 <= 1024 && h->m / (parts * 2) >= 8)
+            parts *= 2;
+        hipLaunchKernelGGL(bxh::wide_flags_kernel, dim3(h->batch * parts), dim3(512), 0, h->stream,
+                           h->dp, h->ds, h->wp, dev_active, parts);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(bxh::wide_compact_kernel, dim3(h->batch), dim3(512), 0, h->stream, h->dp,
+                           h->ds, h->wp, dev_active);
+        HIP_TRY(hipGetLastError());
+        if (remaining) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipMemcpy(h->h_status, h->status.p,
+                              static_cast<size_t>(h->batch) * sizeof(bxh::DevStatus),
+                              hipMemcpyDeviceToHost));
+            for (int b = 0; b != h->batch; ++b)
+                remaining[b] = h->h_status[b].remaining;
+        }
+        return BXH_OK;
     }
     // the row scan on several workgroups per instance when the batch alone
     // does not fill the device, then the ordered compaction per instance
@@ -1520,6 +1643,9 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
                                h->stream));
         s.active = h->active.p;
     }
+    if (h->version == 4) // arrival counters of the wide kernel's workgroups (the error word stays)
+        HIP_TRY(hipMemsetAsync(h->wcnt.p, 0, 4 * static_cast<size_t>(h->batch) * sizeof(unsigned),
+                               h->stream));
     if (h->groups > 1 || h->pipe) { // arrival counters of the cooperating workgroups
         HIP_TRY(hipMemsetAsync(h->cnt.p, 0, 2 * static_cast<size_t>(h->batch) * sizeof(unsigned),
                                h->stream));
@@ -1569,6 +1695,14 @@ bxh_status_sync(bxh_handle h, bxh_status* out)
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rc = drain_events(h))
         return rc;
+    if (h->version == 4) {
+        unsigned err = 0;
+        HIP_TRY(hipMemcpy(&err, h->wcnt.p + 4 * h->batch, sizeof err, hipMemcpyDeviceToHost));
+        if (err)
+            return fail(BXH_ERR_DEVICE,
+                        "a workgroup timed out waiting for its partners (the "
+                        "cooperating workgroups were not all resident)");
+    }
     if (h->groups > 1 || h->version == 3 || h->pipe) {
         unsigned err = 0;
         HIP_TRY(hipMemcpy(&err, h->cnt.p + 2 * h->batch, sizeof err, hipMemcpyDeviceToHost));

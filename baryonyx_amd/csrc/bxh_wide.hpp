@@ -1,0 +1,1144 @@
+// baryonyx_amd/csrc/bxh_wide.hpp -- the row update for instances whose columns
+// do not fit the staged kernel of bxh_kernels.hpp: columns of any length
+// (thousands of entries), any number of rows (pi does not fit LDS), rows of
+// tens of thousands of entries -- the shape of BASELINE.json configs[3]
+// (synthetic SCP 100k x 1M at 2 %).
+//
+// Same algorithm, same order of every floating-point sum as the other kernels
+// (compute_update_row / push_and_compute_update_row of the 01 and 101 solvers,
+// itm-solver-inequalities-01.cpp:208-296, -equalities-01.cpp:184-270,
+// -equalities-101.cpp:208-307, -inequalities-101.cpp:250-347; affect,
+// itm-common.hpp:382-467), so the results are bit-identical to the oracle's.
+//
+// One row update here is a stream, not a latency chain: the r columns of the
+// row hold sum(c_j) entries (4e7 at the XL shape: 480 MB of P and row
+// indices), so G workgroups of an instance split the row's columns (any
+// workgroup can take any column: x and P live in global memory, pi in a private
+// copy per workgroup), every wave streams 32 columns at a time in 16-entry
+// pieces through its own LDS slots (coalesced 16-byte loads: a full 128-byte
+// line of P per column and instruction), and one lane per column and
+// accumulator adds the staged entries strictly in CSC order.  Per row the
+// workgroups meet twice: once to exchange an 8-word record of their part of
+// the row (class counts, extreme keys, tie flag: everything select_variables
+// and affect need when no two reduced costs are equal), once when their P
+// stores of affect() have landed.  A row with a tie (or an interior rank) is
+// published in full and sorted by every workgroup alike.
+#pragma once
+
+#include "bxh_kernels.hpp"
+
+namespace bxh {
+
+constexpr int WIDE_T = 512;      // threads of a workgroup
+constexpr int WIDE_TILE = 32;    // columns a wave streams together
+constexpr int WIDE_SMALL = 1024; // rows up to this length are sorted in LDS
+constexpr int WIDE_ISLOT = 80;   // bytes of an index slot (16 int32 + pad)
+
+template<typename Float>
+struct WideGeom;
+template<>
+struct WideGeom<double>
+{
+    static constexpr int PL = 4;      // P load instructions per piece round
+    static constexpr int PCOLS = 8;   // columns one of them covers
+    static constexpr int PPARTS = 8;  // 16-byte parts of a 16-entry piece
+    static constexpr int PSLOT = 144; // bytes of a P slot (16 entries + pad)
+};
+template<>
+struct WideGeom<float>
+{
+    static constexpr int PL = 2;
+    static constexpr int PCOLS = 16;
+    static constexpr int PPARTS = 4;
+    static constexpr int PSLOT = 80;
+};
+
+struct WideParams
+{
+    int G;                     // workgroups per instance
+    int chmax;                 // longest part of a row one workgroup takes (multiple of 32)
+    unsigned hmask;            // slots of the tie table - 1
+    int n2big;                 // next_pow2(rmax) when rmax > WIDE_SMALL, else 0
+    const int2* col_desc;      // [n] {first padded CSC slot, padded length}
+    void* piw;                 // [batch][G][m+1] Float: pi, one copy per workgroup
+    unsigned long long* whash; // [batch][hmask+1] keys of the row (0 = empty)
+    unsigned long long* wrec;  // [batch][G][8] the workgroups' records of the row
+    unsigned* wcnt;            // [batch][4] arrival counters, then [1] error word
+    unsigned long long* vbuf;  // [batch][rmax] reduced costs of a row that is sorted
+    unsigned long long* bkey;  // [batch][G][n2big] sort scratch of long rows
+    int* bid;                  // [batch][G][n2big]
+    int* vflag32;              // [batch][m] violated flags of the end-of-sweep scan
+};
+
+__host__ __device__ inline int
+wide_stage_bytes(int fsize)
+{
+    return WIDE_TILE * ((fsize == 8 ? 144 : 80) + WIDE_ISLOT);
+}
+
+struct WideLds
+{
+    int off_misc, off_part, off_rec, off_val, off_pown, off_hslot, off_union, union_bytes, total;
+};
+
+__host__ __device__ inline WideLds
+wide_lds(int G, int chmax, int fsize)
+{
+    auto al = [](int v) { return (v + 15) & ~15; };
+    WideLds p;
+    int o = 0;
+    p.off_misc = o;
+    o = al(o + 128 * 4);
+    p.off_part = o;
+    o = al(o + 80 * 8);
+    p.off_rec = o;
+    o = al(o + G * 8 * 8);
+    p.off_val = o;
+    o = al(o + chmax * fsize);
+    p.off_pown = o;
+    o = al(o + chmax * fsize);
+    p.off_hslot = o;
+    o = al(o + chmax * 4);
+    p.off_union = o;
+    p.union_bytes = (WIDE_T / 64) * wide_stage_bytes(fsize);
+    o = al(o + p.union_bytes);
+    p.total = o;
+    return p;
+}
+
+typedef unsigned v4u_w __attribute__((ext_vector_type(4)));
+
+// 16-byte loads with a 64-bit address.  P is written by other workgroups of
+// the instance during the launch: device-scope (sc1) loads, never served from
+// this CU's L1.  The row indices are read-only.  hipcc does not count loads
+// issued from asm: the s_waitcnt statement behind them names every destination.
+__device__ inline v4u_w
+wide_load_sc1(const void* p)
+{
+    v4u_w r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ inline v4u_w
+wide_load(const void* p)
+{
+    v4u_w r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+
+// Insert a key of the row into the instance's table (open addressing, one
+// 64-bit compare-and-swap per probe, executed at the memory side: coherent for
+// workgroups on any XCD).  Returns true when an equal key is already there.
+// *slot: where this key went (to clear it after the row), -1 if nowhere.
+__device__ inline bool
+wide_hash_insert(unsigned long long* tab, unsigned mask, unsigned long long key, int* slot)
+{
+    *slot = -1;
+    if (key == 0ull) // (only a NaN maps to 0, the empty mark: let the sort path have the row)
+        return true;
+    unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 38) & mask;
+    for (unsigned probes = 0; probes <= mask; ++probes) {
+        const unsigned long long old = atomicCAS(&tab[h], 0ull, key);
+        if (old == 0ull) {
+            *slot = (int)h;
+            return false;
+        }
+        if (old == key)
+            return true;
+        h = (h + 1) & mask;
+    }
+    return true; // table full (cannot happen: 4 slots per row entry)
+}
+
+// Arrival of this workgroup at one of the instance's counters and wait for
+// all G of them: every wave first waits for its own stores, one lane adds and
+// polls (bounded: a missing partner sets the error word), the others wait at
+// the barrier.  Returns false when the wait was given up.
+__device__ inline bool
+wide_sync(unsigned* cnt, unsigned target, unsigned* err, int* dead_s)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023) == 0 &&
+                (spins > 8000000L ||
+                 __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *dead_s = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return *dead_s == 0;
+}
+
+enum
+{
+    WM_DEAD = 96,  // a partner timed out: leave the sweep
+    WM_NSLOW = 97
+};
+
+// One sweep of every instance: compute_order::run / push_and_run
+// (itm-common.hpp:682-880) for the orders none / reversing / random_sorting.
+template<typename Float, bool PM1>
+__global__ __launch_bounds__(WIDE_T) void
+sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
+{
+    using Geo = WideGeom<Float>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int G = wp.G;
+    int inst, grp;
+    {
+        const int b = blockIdx.x, ninst = gridDim.x / G;
+        if ((ninst & 7) == 0) { // partners on one XCD under round-robin dispatch (speed only)
+            inst = (b & 7) + 8 * ((b >> 3) / G);
+            grp = (b >> 3) % G;
+        } else {
+            inst = b / G;
+            grp = b % G;
+        }
+    }
+    if (a.active && !a.active[inst])
+        return;
+
+    const int tid = threadIdx.x;
+    constexpr int T = WIDE_T;
+    const int lane = tid & 63, wave = tid >> 6;
+    const WideLds lp = wide_lds(G, wp.chmax, (int)sizeof(Float));
+    int* misc_s = (int*)(smem + lp.off_misc);
+    Float* d_s = (Float*)(misc_s + MS_D);
+    unsigned long long* part_s = (unsigned long long*)(smem + lp.off_part);
+    unsigned long long* rec_s = (unsigned long long*)(smem + lp.off_rec);
+    Float* val_s = (Float*)(smem + lp.off_val);
+    Float* pown_s = (Float*)(smem + lp.off_pown);
+    int* hslot_s = (int*)(smem + lp.off_hslot);
+    unsigned char* uni = smem + lp.off_union;
+    // sort path of short rows: the staging slots are idle then
+    Float* val_all = (Float*)uni;
+    const int n2s = WIDE_SMALL;
+    unsigned long long* key_s = (unsigned long long*)(uni + WIDE_SMALL * sizeof(Float));
+    int* id_s = (int*)((unsigned char*)key_s + n2s * 8);
+    unsigned long long* key_run = (unsigned long long*)((unsigned char*)id_s + n2s * 4);
+    int* id_run = (int*)((unsigned char*)key_run + n2s * 8);
+
+    const bool maximize = pb.maximize != 0;
+    const int kind = pb.kind;
+    const int m = pb.m;
+
+    Float* P = (Float*)st.P + (size_t)inst * (size_t)pb.nnzp;
+    Float* pig = (Float*)st.pi + (size_t)inst * m;
+    Float* piw = (Float*)wp.piw + ((size_t)inst * G + grp) * (size_t)(m + 1);
+    unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
+    Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
+    unsigned long long* htab = wp.whash + (size_t)inst * ((size_t)wp.hmask + 1);
+    unsigned long long* recg = wp.wrec + (size_t)inst * G * 8;
+    unsigned long long* vbuf = wp.vbuf + (size_t)inst * pb.rmax;
+    unsigned* cnt_s1 = wp.wcnt + (size_t)inst * 4;
+    unsigned* cnt_s2 = cnt_s1 + 1;
+    unsigned* cnt_sl = cnt_s1 + 2;
+    unsigned* cnt_end = cnt_s1 + 3;
+    unsigned* err_word = wp.wcnt + (size_t)(gridDim.x / G) * 4;
+    const Float* cost = (const Float*)pb.cost;
+
+    const int ord = order_of(a, inst);
+    int* vlist = st.vlist + (size_t)inst * st.lcap;
+    int* vrows = st.vwork + ((size_t)inst * G + grp) * st.lcap;
+
+    const Float kappa = (Float)a.kappa[inst];
+    const Float kfac = kappa / ((Float)1 - kappa);
+    const Float delta = (Float)a.delta;
+    const Float theta = (Float)a.theta;
+    const Float obj_amp = (Float)a.obj_amp;
+    const bool push = a.is_push != 0;
+
+    // private copy of pi (a workgroup only ever reads its own copy: plain,
+    // L1-cached loads in the column sums)
+    for (int i = tid; i < m; i += T)
+        piw[i] = pig[i];
+    if (tid == 0)
+        piw[m] = 0; // read through the padding of the columns
+
+    MinStd rng;
+    rng.s = st.status[inst].rng;
+    const int nrows = st.vcount[inst];
+    double alg_bytes = 0.0; // thread 0 of workgroup 0
+
+    for (int i = tid; i < nrows; i += T)
+        vrows[i] = vlist[i];
+    if (tid == 0) {
+        misc_s[MS_PICH] = 0;
+        misc_s[WM_DEAD] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (ord == 2) // random_sorting (itm-common.hpp:708-714 / :817-823), every copy alike
+            rng.shuffle(vrows, (unsigned)nrows);
+        misc_s[MS_RNG] = (int)rng.s;
+    }
+    __syncthreads();
+    rng.s = (unsigned)misc_s[MS_RNG];
+
+    unsigned nslow = 0;
+    bool dead = false;
+    unsigned char* stg_p = uni + (size_t)wave * wide_stage_bytes((int)sizeof(Float));
+    unsigned char* stg_i = stg_p + WIDE_TILE * Geo::PSLOT;
+
+    for (int it = 0; it < nrows && !dead; ++it) {
+        const int k = (ord == 1) ? vrows[nrows - 1 - it] : vrows[it];
+        const int rs = pb.row_ptr[k];
+        const int r = pb.row_ptr[k + 1] - rs;
+        // this workgroup's part of the row: entries [start, start + cnt)
+        const int ch = (((r + G - 1) / G) + WIDE_TILE - 1) & ~(WIDE_TILE - 1);
+        const int start = min(r, grp * ch);
+        const int cnt = min(ch, r - start);
+        const int bk_min = pb.bmin[k], bk_max = pb.bmax[k];
+        const int bk_neg = PM1 ? pb.bneg[k] : 0;
+
+        // ---- decrease_preference: P[row k] *= theta, kept for affect --------
+        // (the P stores of the previous row's affect have landed: the second
+        // meeting of that row)
+        for (int l = tid; l < cnt; l += T) {
+            const int pe = pb.row_pos[rs + start + l];
+            Float p = __hip_atomic_load(&P[pe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p = p * theta;
+            __hip_atomic_store(&P[pe], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pown_s[l] = p;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- compute_reduced_costs: this workgroup's columns, 32 per wave ---
+        const int ntile = (cnt + WIDE_TILE - 1) / WIDE_TILE;
+        for (int tile = wave; tile < ntile; tile += T / 64) {
+            const int c = lane & 31;
+            const bool prole = lane < 32;
+            const int l = tile * WIDE_TILE + c;
+            const bool valid = l < cnt;
+            int cs = 0, np = 0;
+            Float cj = 0;
+            bool negf = false;
+            if (valid) {
+                const int e = rs + start + l;
+                const int j = pb.row_col[e];
+                const int2 cd = wp.col_desc[j];
+                cs = cd.x;
+                np = cd.y >> 4;
+                cj = cost[j];
+                if (PM1)
+                    negf = pb.fac_csr[e] < 0;
+            }
+            int tnp = np;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1)
+                tnp = max(tnp, __shfl_xor(tnp, o, 64));
+            // the columns this lane loads for: their first slot and piece count
+            const char* pbase[Geo::PL];
+            int pnp[Geo::PL];
+#pragma unroll
+            for (int i = 0; i < Geo::PL; ++i) {
+                const int ci = i * Geo::PCOLS + lane / Geo::PPARTS;
+                const int ccs = __shfl(cs, ci, 64);
+                pnp[i] = max(1, __shfl(np, ci, 64));
+                pbase[i] = (const char*)P + (size_t)ccs * sizeof(Float) + (lane % Geo::PPARTS) * 16;
+            }
+            const char* ibase[2];
+            int inp[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ci = i * 16 + (lane >> 2);
+                const int ccs = __shfl(cs, ci, 64);
+                inp[i] = max(1, __shfl(np, ci, 64));
+                ibase[i] = (const char*)pb.col_row + (size_t)ccs * 4 + (lane & 3) * 16;
+            }
+            Float sum = 0; // lanes 0-31: sum_a_p of column c, lanes 32-63: sum_a_pi
+            for (int piece = 0; piece < tnp; ++piece) {
+                v4u_w pv[Geo::PL], iv[2];
+#pragma unroll
+                for (int i = 0; i < Geo::PL; ++i)
+                    pv[i] = wide_load_sc1(pbase[i] +
+                                          (size_t)min(piece, pnp[i] - 1) * (16 * sizeof(Float)));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    iv[i] = wide_load(ibase[i] + (size_t)min(piece, inp[i] - 1) * 64);
+                if constexpr (Geo::PL == 4)
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(iv[0]),
+                                   "+v"(iv[1])::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(pv[0]), "+v"(pv[1]), "+v"(iv[0]), "+v"(iv[1])::"memory");
+#pragma unroll
+                for (int i = 0; i < Geo::PL; ++i)
+                    *(v4u_w*)(stg_p + (i * Geo::PCOLS + lane / Geo::PPARTS) * Geo::PSLOT +
+                              (lane % Geo::PPARTS) * 16) = pv[i];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    *(v4u_w*)(stg_i + (i * 16 + (lane >> 2)) * WIDE_ISLOT + (lane & 3) * 16) = iv[i];
+                // (the slots are this wave's own: no barrier, but the compiler must
+                // keep the other lanes' writes in front of this lane's reads)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (piece < np) {
+                    const int* ip = (const int*)(stg_i + c * WIDE_ISLOT);
+                    if (prole) {
+                        const Float* sp = (const Float*)(stg_p + c * Geo::PSLOT);
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const Float p = sp[t];
+                            if (PM1) {
+                                const Float fa = (ip[t] & 0x40000000) ? (Float)-1 : (Float)1;
+                                sum += fa * p;
+                            } else
+                                sum += p;
+                        }
+                    } else {
+                        Float piv[16];
+                        int ri[16];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t)
+                            ri[t] = ip[t];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t)
+                            piv[t] = piw[ri[t] & 0x3fffffff];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            if (PM1) {
+                                const Float fa = (ri[t] & 0x40000000) ? (Float)-1 : (Float)1;
+                                sum += fa * piv[t];
+                            } else
+                                sum += piv[t];
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier(); // reads done before the next piece is staged
+            }
+            const Float sum_a_pi = __shfl(sum, c + 32, 64);
+            if (prole && valid) {
+                Float v = cj - sum_a_pi - sum;
+                if (PM1 && negf)
+                    v = -v;
+                if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
+                    v += obj_amp * (PM1 ? cj : cost[start + l]);
+                val_s[l] = v;
+            }
+        }
+        if (tid < 80)
+            part_s[tid] = (tid == 66 || tid == 69) ? ~0ull : 0ull;
+        __syncthreads();
+
+        // ---- this workgroup's record of the row ----------------------------
+        const unsigned long long K0 = order_key<Float>((Float)0, maximize);
+        {
+            unsigned long long A = ~0ull, A2 = ~0ull, B = ~0ull, C = ~0ull, D = ~0ull;
+            int cN = 0, cZ = 0;
+            bool tie = false;
+            for (int l = tid; l < cnt; l += T) {
+                const unsigned long long key = order_key<Float>(val_s[l], maximize);
+                int slot;
+                tie |= wide_hash_insert(htab, wp.hmask, key, &slot);
+                hslot_s[l] = slot;
+                if (key < A) {
+                    A2 = A;
+                    A = key;
+                } else if (key < A2)
+                    A2 = key;
+                B = umin64(B, ~key);
+                if (key < K0) {
+                    ++cN;
+                    C = umin64(C, ~key);
+                } else if (key == K0)
+                    ++cZ;
+                else
+                    D = umin64(D, key);
+            }
+            const unsigned long long ownA = A;
+            wave_umin64x4(A, B, C, D);
+            unsigned long long E = ownA == A ? A2 : ownA;
+            E = wave_umin64(E);
+            cN = wave_sum(cN);
+            cZ = wave_sum(cZ);
+            const bool wtie = __any(tie);
+            if (lane == 0) {
+                atomicMax(&part_s[64], ~B); // largest key
+                atomicMax(&part_s[65], ~C); // largest key of class N
+                atomicMin(&part_s[66], D);  // smallest key of class S
+                atomicMin(&part_s[69], A);  // smallest key
+                part_s[wave * 2] = A;
+                part_s[wave * 2 + 1] = E;
+                atomicAdd(&part_s[67], ((unsigned long long)(unsigned)cN << 32) | (unsigned)cZ);
+                if (wtie)
+                    atomicOr(&part_s[68], 1ull);
+            }
+        }
+        __syncthreads();
+        if (tid < 8) {
+            unsigned long long v;
+            const unsigned long long a1 = part_s[69];
+            if (tid == 0)
+                v = a1;
+            else if (tid == 1) { // second smallest key of this part
+                v = ~0ull;
+                for (int w = 0; w < T / 64; ++w) {
+                    const unsigned long long w1 = part_s[w * 2], w2 = part_s[w * 2 + 1];
+                    v = umin64(v, w1 == a1 ? w2 : w1);
+                }
+            } else if (tid == 2)
+                v = part_s[64];
+            else if (tid == 3)
+                v = part_s[65];
+            else if (tid == 4)
+                v = part_s[66];
+            else if (tid == 5)
+                v = part_s[67];
+            else if (tid == 6)
+                v = part_s[68];
+            else
+                v = (unsigned long long)cnt;
+            __hip_atomic_store(&recg[grp * 8 + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- first meeting of the row: every part is summed ----------------
+        if (!wide_sync(cnt_s1, (unsigned)G * (unsigned)(it + 1), err_word, misc_s + WM_DEAD)) {
+            dead = true;
+            break;
+        }
+        for (int i = tid; i < G * 8; i += T)
+            rec_s[i] = __hip_atomic_load(&recg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+
+        // ---- selection without sorting: the same scalar code in every thread
+        // of every workgroup (see sweep_kernel_v2) ----------------------------
+        bool fast = false;
+        int f_mode = 0, f_nN = 0, f_nZ = 0;
+        unsigned long long f_thr = 0ull;
+        Float f_d = 0, f_newpi = 0;
+        bool f_pich = false;
+        if (r >= 2) {
+            unsigned long long g1 = ~0ull, gx = 0ull, gxN = 0ull, gnS = ~0ull;
+            int nN = 0, nZ = 0;
+            bool anytie = false;
+            for (int g = 0; g < G; ++g) {
+                g1 = umin64(g1, rec_s[g * 8]);
+                gx = umax64(gx, rec_s[g * 8 + 2]);
+                gxN = umax64(gxN, rec_s[g * 8 + 3]);
+                gnS = umin64(gnS, rec_s[g * 8 + 4]);
+                nN += (int)(rec_s[g * 8 + 5] >> 32);
+                nZ += (int)(rec_s[g * 8 + 5] & 0xffffffffu);
+                anytie |= rec_s[g * 8 + 6] != 0ull;
+            }
+            auto second_smallest = [&]() -> unsigned long long {
+                unsigned long long v = ~0ull;
+                for (int g = 0; g < G; ++g) {
+                    const unsigned long long a1 = rec_s[g * 8], a2 = rec_s[g * 8 + 1];
+                    v = umin64(v, a1 == g1 ? a2 : a1);
+                }
+                return v;
+            };
+            bool ok = !anytie;
+            const unsigned saved_rng = rng.s;
+            int sel = 0;
+            unsigned long long k_sel = 0ull, k_sel1 = 0ull;
+            if (ok) {
+                const int c_size = bk_neg;
+                int bkmin = bk_min, bkmax = bk_max;
+                if (kind == 0 || kind == 2 || bkmin == bkmax) {
+                    sel = min(bkmin + c_size, r) - 1;
+                } else {
+                    if (kind == 1) {
+                        bkmin = min(bkmin, r);
+                        bkmax = min(bkmax, r);
+                    } else {
+                        bkmin += c_size;
+                        bkmax = min(bkmax + c_size, r);
+                    }
+                    sel = bkmax - 1;
+                    int cur = bkmin;
+                    if (cur <= bkmax) {
+                        bool stopped = false;
+                        if (cur < nN)
+                            cur = nN; // N entries never stop the scan
+                        if (cur <= bkmax && cur < nN + nZ) { // the zero entry
+                            if (rng.coin())
+                                stopped = true;
+                            else
+                                ++cur;
+                        }
+                        if (!stopped && cur <= bkmax) {
+                            if (cur < r)
+                                stopped = true; // first S entry
+                            else { // R[r_size]: what an earlier, longer row left there
+                                const Float sv = __hip_atomic_load(&staleg[r], __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT);
+                                if (sv == 0)
+                                    stopped = rng.coin();
+                                else
+                                    stopped = maximize ? sv < 0 : sv > 0;
+                            }
+                        }
+                        if (stopped)
+                            sel = cur - 1;
+                    }
+                }
+                auto key_at = [&](int rank, bool& good) -> unsigned long long {
+                    if (rank == 0)
+                        return g1;
+                    if (rank == 1)
+                        return second_smallest();
+                    if (rank == r - 1)
+                        return gx;
+                    if (nN > 0 && rank == nN - 1)
+                        return gxN;
+                    if (rank == nN)
+                        return nZ ? K0 : gnS;
+                    if (nZ && rank == nN + nZ)
+                        return gnS;
+                    good = false;
+                    return 0ull;
+                };
+                if (sel < 0) {
+                    k_sel = key_at(0, ok);
+                } else if (sel + 1 >= r) {
+                    k_sel = key_at(r - 1, ok);
+                } else {
+                    k_sel = key_at(sel, ok);
+                    k_sel1 = key_at(sel + 1, ok);
+                }
+            }
+            if (!ok) {
+                rng.s = saved_rng; // the sort path redoes the scan
+            } else {
+                const Float one = 1, two = 2;
+                const Float middle = (two + one) / two;
+                Float d = delta;
+                const Float v_sel = key_value<Float>(k_sel, maximize);
+                if (sel < 0) {
+                    d += kfac * (v_sel / two);
+                    f_mode = 0;
+                } else if (sel + 1 >= r) {
+                    d += kfac * (v_sel * middle);
+                    f_mode = 1;
+                } else {
+                    const Float v_sel1 = key_value<Float>(k_sel1, maximize);
+                    const Float old_pi = piw[k];
+                    const Float new_pi = old_pi + ((v_sel + v_sel1) / two);
+                    d += kfac * (v_sel1 - v_sel);
+                    f_mode = 2;
+                    f_thr = k_sel;
+                    f_newpi = new_pi;
+                    f_pich = signbit(old_pi) != signbit(new_pi);
+                }
+                f_d = d;
+                f_nN = nN;
+                f_nZ = nZ;
+                fast = true;
+            }
+        }
+
+        if (fast) {
+            // ---- affect without the sorted order ------------------------------
+            __syncthreads(); // every thread has read pi_k
+            if (tid == 0) {
+                if (grp == 0)
+                    alg_bytes += pb.row_bytes[k];
+                if (f_mode == 2) {
+                    piw[k] = f_newpi;
+                    if (f_pich)
+                        misc_s[MS_PICH] = 1;
+                }
+            }
+            for (int l = tid; l < cnt; l += T) {
+                const int e = rs + start + l;
+                const unsigned long long key = order_key<Float>(val_s[l], maximize);
+                const int j = pb.row_col[e];
+                const int pe = pb.row_pos[e];
+                bool up = f_mode == 1 || (f_mode == 2 && key <= f_thr);
+                if (PM1 && pb.fac_csr[e] < 0)
+                    up = !up;
+                const Float p = pown_s[l]; // P[pe] * theta
+                if (up)
+                    atomicOr(&xg[j >> 5], 1u << (j & 31));
+                else
+                    atomicAnd(&xg[j >> 5], ~(1u << (j & 31)));
+                __hip_atomic_store(&P[pe], up ? p + f_d : p - f_d, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                // R[pos].value after the sort only matters through
+                // stop_iterating: its class (N / zero / S)
+                const int pos = start + l;
+                const Float repN = maximize ? (Float)1 : (Float)-1;
+                __hip_atomic_store(&staleg[pos],
+                                   pos < f_nN ? repN : (pos < f_nN + f_nZ ? (Float)0 : -repN),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            // ---- calculator_sort: the whole row, in every workgroup alike ----
+            for (int l = tid; l < cnt; l += T)
+                __hip_atomic_store(&vbuf[start + l],
+                                   (unsigned long long)__double_as_longlong((double)val_s[l]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!wide_sync(cnt_sl, (unsigned)G * (nslow + 1u), err_word, misc_s + WM_DEAD)) {
+                dead = true;
+                break;
+            }
+            ++nslow;
+            if (tid == 0)
+                misc_s[MS_TIE] = 0;
+            if (r <= WIDE_SMALL) {
+                for (int i = tid; i < r; i += T)
+                    val_all[i] = (Float)__longlong_as_double((long long)__hip_atomic_load(
+                      &vbuf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                __syncthreads();
+                if (r > 1) {
+                    Prof prof_;
+                    run_merge_sort<Float>(val_all, r, maximize, key_run, id_run, key_s, id_s, &prof_);
+                } else {
+                    if (tid == 0) {
+                        key_s[0] = order_key<Float>(val_all[0], maximize);
+                        id_s[0] = 0;
+                    }
+                    __syncthreads();
+                }
+                for (int i = tid; i + 1 < r; i += T)
+                    if (key_s[i] == key_s[i + 1])
+                        misc_s[MS_TIE] = 1;
+                __syncthreads();
+                bool shuffled = false;
+                if (misc_s[MS_TIE]) {
+                    unsigned stt = rng.s;
+                    shuffled = parallel_tie_shuffle(key_s, id_s, r, &stt, pb.lcg_pow, (int*)key_run,
+                                                    (int*)key_run + n2s, id_run, misc_s + MS_WAVES);
+                    if (shuffled)
+                        rng.s = stt;
+                }
+                if (tid == 0) {
+                    if (grp == 0)
+                        alg_bytes += pb.row_bytes[k];
+                    if (misc_s[MS_TIE] && !shuffled) {
+                        int b0 = 0;
+                        for (int i = 1; i <= r; ++i) {
+                            if (i == r || key_s[i] != key_s[b0]) {
+                                rng.shuffle(id_s + b0, (unsigned)(i - b0));
+                                b0 = i;
+                            }
+                        }
+                    }
+                    auto Rv = [&](int i) -> Float { // R[i].value, R[r] is stale
+                        return i < r ? val_all[id_s[i]]
+                                     : __hip_atomic_load(&staleg[i], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                    };
+                    auto stop = [&](Float v) -> bool { // itm-common.hpp:150-163
+                        if (v == 0)
+                            return rng.coin();
+                        return maximize ? v < 0 : v > 0;
+                    };
+                    const int c_size = bk_neg;
+                    int bkmin = bk_min, bkmax = bk_max;
+                    int sel;
+                    if (kind == 0 || kind == 2 || bkmin == bkmax) {
+                        sel = min(bkmin + c_size, r) - 1;
+                    } else {
+                        if (kind == 1) {
+                            bkmin = min(bkmin, r);
+                            bkmax = min(bkmax, r);
+                        } else {
+                            bkmin += c_size;
+                            bkmax = min(bkmax + c_size, r);
+                        }
+                        sel = bkmax - 1;
+                        int nN = 0, nNZ = 0;
+                        {
+                            int lo = 0, hi = r; // first key >= K0
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (key_s[mid] < K0)
+                                    lo = mid + 1;
+                                else
+                                    hi = mid;
+                            }
+                            nN = lo;
+                            hi = r; // first key > K0
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (key_s[mid] <= K0)
+                                    lo = mid + 1;
+                                else
+                                    hi = mid;
+                            }
+                            nNZ = lo;
+                        }
+                        int cur = bkmin;
+                        if (cur <= bkmax) {
+                            bool stopped = false;
+                            if (cur < nN)
+                                cur = nN;
+                            while (!stopped && cur <= bkmax && cur < nNZ) {
+                                if (rng.coin())
+                                    stopped = true;
+                                else
+                                    ++cur;
+                            }
+                            if (!stopped && cur <= bkmax) {
+                                if (cur < r)
+                                    stopped = true; // first S entry
+                                else
+                                    stopped = stop(Rv(r)); // R[r_size] (stale)
+                            }
+                            if (stopped)
+                                sel = cur - 1;
+                        }
+                    }
+                    const Float one = 1, two = 2;
+                    const Float middle = (two + one) / two;
+                    Float d = delta;
+                    if (sel < 0) {
+                        d += kfac * (Rv(0) / two);
+                    } else if (sel + 1 >= r) {
+                        d += kfac * (Rv(sel) * middle);
+                    } else {
+                        const Float old_pi = piw[k];
+                        const Float new_pi = old_pi + ((Rv(sel) + Rv(sel + 1)) / two);
+                        piw[k] = new_pi;
+                        d += kfac * (Rv(sel + 1) - Rv(sel));
+                        if (signbit(old_pi) != signbit(new_pi))
+                            misc_s[MS_PICH] = 1;
+                    }
+                    misc_s[MS_SEL] = sel;
+                    *d_s = d;
+                    misc_s[MS_RNG] = (int)rng.s;
+                }
+                __syncthreads();
+                rng.s = (unsigned)misc_s[MS_RNG];
+                {
+                    const int sel = misc_s[MS_SEL];
+                    const Float d = *d_s;
+                    for (int i = tid; i < r; i += T) {
+                        const int idx = id_s[i];
+                        if (i >= start && i < start + cnt) // this workgroup's positions of R
+                            __hip_atomic_store(&staleg[i], val_all[idx], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        const int l = idx - start;
+                        if (l < 0 || l >= cnt)
+                            continue; // another workgroup's entry
+                        const int e = rs + idx;
+                        const int j = pb.row_col[e];
+                        const int pe = pb.row_pos[e];
+                        bool up = i <= sel;
+                        if (PM1 && pb.fac_csr[e] < 0)
+                            up = !up;
+                        const Float p = pown_s[l];
+                        if (up)
+                            atomicOr(&xg[j >> 5], 1u << (j & 31));
+                        else
+                            atomicAnd(&xg[j >> 5], ~(1u << (j & 31)));
+                        __hip_atomic_store(&P[pe], up ? p + d : p - d, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            } else {
+                // ---- a long row: sorted in global scratch (every workgroup its
+                // own copy), tied runs shuffled by one thread ------------------
+                const int n2 = next_pow2(r);
+                unsigned long long* bkey = wp.bkey + ((size_t)inst * G + grp) * (size_t)wp.n2big;
+                int* bid = wp.bid + ((size_t)inst * G + grp) * (size_t)wp.n2big;
+                for (int i = tid; i < n2; i += T) {
+                    unsigned long long key = ~0ull;
+                    if (i < r)
+                        key = order_key<Float>(
+                          (Float)__longlong_as_double((long long)__hip_atomic_load(
+                            &vbuf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)),
+                          maximize);
+                    bkey[i] = key;
+                    bid[i] = i;
+                }
+                __syncthreads();
+                bitonic_sort(bkey, bid, n2);
+                for (int i = tid; i + 1 < r; i += T)
+                    if (bkey[i] == bkey[i + 1])
+                        misc_s[MS_TIE] = 1;
+                __syncthreads();
+                auto val_of = [&](int idx) -> Float {
+                    return (Float)__longlong_as_double((long long)__hip_atomic_load(
+                      &vbuf[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                };
+                if (tid == 0) {
+                    if (grp == 0)
+                        alg_bytes += pb.row_bytes[k];
+                    if (misc_s[MS_TIE]) {
+                        int b0 = 0;
+                        for (int i = 1; i <= r; ++i) {
+                            if (i == r || bkey[i] != bkey[b0]) {
+                                rng.shuffle(bid + b0, (unsigned)(i - b0));
+                                b0 = i;
+                            }
+                        }
+                    }
+                    auto Rv = [&](int i) -> Float {
+                        return i < r ? val_of(bid[i])
+                                     : __hip_atomic_load(&staleg[i], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                    };
+                    auto stop = [&](Float v) -> bool {
+                        if (v == 0)
+                            return rng.coin();
+                        return maximize ? v < 0 : v > 0;
+                    };
+                    const int c_size = bk_neg;
+                    int bkmin = bk_min, bkmax = bk_max;
+                    int sel;
+                    if (kind == 0 || kind == 2 || bkmin == bkmax) {
+                        sel = min(bkmin + c_size, r) - 1;
+                    } else {
+                        if (kind == 1) {
+                            bkmin = min(bkmin, r);
+                            bkmax = min(bkmax, r);
+                        } else {
+                            bkmin += c_size;
+                            bkmax = min(bkmax + c_size, r);
+                        }
+                        sel = bkmax - 1;
+                        int nN = 0, nNZ = 0;
+                        {
+                            int lo = 0, hi = r;
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (bkey[mid] < K0)
+                                    lo = mid + 1;
+                                else
+                                    hi = mid;
+                            }
+                            nN = lo;
+                            hi = r;
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (bkey[mid] <= K0)
+                                    lo = mid + 1;
+                                else
+                                    hi = mid;
+                            }
+                            nNZ = lo;
+                        }
+                        int cur = bkmin;
+                        if (cur <= bkmax) {
+                            bool stopped = false;
+                            if (cur < nN)
+                                cur = nN;
+                            while (!stopped && cur <= bkmax && cur < nNZ) {
+                                if (rng.coin())
+                                    stopped = true;
+                                else
+                                    ++cur;
+                            }
+                            if (!stopped && cur <= bkmax) {
+                                if (cur < r)
+                                    stopped = true;
+                                else
+                                    stopped = stop(Rv(r));
+                            }
+                            if (stopped)
+                                sel = cur - 1;
+                        }
+                    }
+                    const Float one = 1, two = 2;
+                    const Float middle = (two + one) / two;
+                    Float d = delta;
+                    if (sel < 0) {
+                        d += kfac * (Rv(0) / two);
+                    } else if (sel + 1 >= r) {
+                        d += kfac * (Rv(sel) * middle);
+                    } else {
+                        const Float old_pi = piw[k];
+                        const Float new_pi = old_pi + ((Rv(sel) + Rv(sel + 1)) / two);
+                        piw[k] = new_pi;
+                        d += kfac * (Rv(sel + 1) - Rv(sel));
+                        if (signbit(old_pi) != signbit(new_pi))
+                            misc_s[MS_PICH] = 1;
+                    }
+                    misc_s[MS_SEL] = sel;
+                    *d_s = d;
+                    misc_s[MS_RNG] = (int)rng.s;
+                }
+                __syncthreads();
+                rng.s = (unsigned)misc_s[MS_RNG];
+                {
+                    const int sel = misc_s[MS_SEL];
+                    const Float d = *d_s;
+                    for (int i = tid; i < r; i += T) {
+                        const int idx = bid[i];
+                        if (i >= start && i < start + cnt)
+                            __hip_atomic_store(&staleg[i], val_of(idx), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        const int l = idx - start;
+                        if (l < 0 || l >= cnt)
+                            continue;
+                        const int e = rs + idx;
+                        const int j = pb.row_col[e];
+                        const int pe = pb.row_pos[e];
+                        bool up = i <= sel;
+                        if (PM1 && pb.fac_csr[e] < 0)
+                            up = !up;
+                        const Float p = pown_s[l];
+                        if (up)
+                            atomicOr(&xg[j >> 5], 1u << (j & 31));
+                        else
+                            atomicAnd(&xg[j >> 5], ~(1u << (j & 31)));
+                        __hip_atomic_store(&P[pe], up ? p + d : p - d, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+        // the row's keys leave the tie table
+        for (int l = tid; l < cnt; l += T) {
+            const int s = hslot_s[l];
+            if (s >= 0)
+                __hip_atomic_exchange(&htab[s], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- second meeting of the row: affect's stores have landed --------
+        if (!wide_sync(cnt_s2, (unsigned)G * (unsigned)(it + 1), err_word, misc_s + WM_DEAD)) {
+            dead = true;
+            break;
+        }
+    }
+    if (dead)
+        return; // the error word is set: the host reports BXH_ERR_DEVICE
+
+    // ---- write back, then compute_violated_constraints (itm-common.hpp:102-115)
+    if (grp == 0)
+        for (int i = tid; i < m; i += T)
+            pig[i] = piw[i];
+    {
+        const int per = (m + G - 1) / G;
+        const int k0 = grp * per, k1 = min(m, k0 + per);
+        int* vf = wp.vflag32 + (size_t)inst * m;
+        for (int k = k0 + wave; k < k1; k += T / 64) {
+            const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
+            int v = 0;
+            for (int e = rs + lane; e < re; e += 64) {
+                const int j = pb.row_col[e];
+                const int bit =
+                  (__hip_atomic_load(&xg[j >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >>
+                   (j & 31)) &
+                  1u;
+                v += PM1 ? (int)pb.fac_csr[e] * bit : bit;
+            }
+            v = wave_sum(v);
+            if (lane == 0)
+                __hip_atomic_store(&vf[k], (int)!(pb.bmin[k] <= v && v <= pb.bmax[k]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!wide_sync(cnt_end, (unsigned)G, err_word, misc_s + WM_DEAD))
+            return;
+        if (grp != 0)
+            return;
+        int base = 0;
+        int* scratch_s = misc_s + MS_WAVES;
+        for (int c = 0; c < m; c += T) {
+            const int k = c + tid;
+            const bool f = k < m && __hip_atomic_load(&vf[k], __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT) != 0;
+            const unsigned long long mask = __ballot(f);
+            const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0)
+                scratch_s[wave] = __popcll(mask);
+            __syncthreads();
+            int off = 0, tot = 0;
+            for (int w = 0; w < T / 64; ++w) {
+                const int cw = scratch_s[w];
+                if (w < wave)
+                    off += cw;
+                tot += cw;
+            }
+            if (f)
+                vlist[base + off + prefix] = k;
+            base += tot;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            st.vcount[inst] = base;
+            DevStatus s = st.status[inst];
+            s.remaining = base;
+            s.pi_changed = misc_s[MS_PICH];
+            s.rng = rng.s;
+            s.rows_in_sweep = (unsigned)nrows;
+            s.row_updates += (unsigned long long)nrows;
+            s.alg_bytes += alg_bytes;
+            st.status[inst] = s;
+        }
+    }
+}
+
+// compute_order::init (itm-common.hpp:660-680) for the wide layout: the flags
+// of the violated rows on `parts` workgroups per instance (x from global
+// memory), then the ordered compaction.
+__global__ __launch_bounds__(512) void
+wide_flags_kernel(DevProblem pb, DevState st, WideParams wp, const unsigned char* active, int parts)
+{
+    const int inst = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (active && !active[inst])
+        return;
+    const bool pm1 = pb.kind == 2 || pb.kind == 3;
+    const unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
+    int* vf = wp.vflag32 + (size_t)inst * pb.m;
+    const int per = (pb.m + parts - 1) / parts;
+    const int k0 = part * per, k1 = min(pb.m, k0 + per);
+    for (int k = k0 + wave; k < k1; k += T >> 6) {
+        const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
+        int v = 0;
+        for (int e = rs + lane; e < re; e += 64) {
+            const int j = pb.row_col[e];
+            const int bit = (xg[j >> 5] >> (j & 31)) & 1u;
+            v += pm1 ? (int)pb.fac_csr[e] * bit : bit;
+        }
+        v = wave_sum(v);
+        if (lane == 0)
+            vf[k] = !(pb.bmin[k] <= v && v <= pb.bmax[k]);
+    }
+}
+
+__global__ __launch_bounds__(512) void
+wide_compact_kernel(DevProblem pb, DevState st, WideParams wp, const unsigned char* active)
+{
+    __shared__ int scratch_s[16];
+    const int inst = blockIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (active && !active[inst])
+        return;
+    const int* vf = wp.vflag32 + (size_t)inst * pb.m;
+    int* vlist = st.vlist + (size_t)inst * st.lcap;
+    int base = 0;
+    for (int c = 0; c < pb.m; c += T) {
+        const int k = c + tid;
+        const bool f = k < pb.m && vf[k] != 0;
+        const unsigned long long mask = __ballot(f);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            scratch_s[wave] = __popcll(mask);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w = 0; w < (T >> 6); ++w) {
+            const int cw = scratch_s[w];
+            if (w < wave)
+                off += cw;
+            tot += cw;
+        }
+        if (f)
+            vlist[base + off + prefix] = k;
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        st.vcount[inst] = base;
+        st.status[inst].remaining = base;
+    }
+}
+
+} // namespace bxh

@@ -148,7 +148,9 @@ int bxh_rmax(bxh_handle h);
  *   2  staged pipeline, one workgroup per instance
  *   3  inequalities-Z kernel
  *   20 + g  staged pipeline, g lock-step column owners per instance
- *   40 + w  pipelined sweep, w workgroups per instance (1 row chain + w - 1 producers) */
+ *   40 + w  pipelined sweep, w workgroups per instance (1 row chain + w - 1 producers)
+ *   100 + g wide kernel (columns / row counts beyond the staged kernel: the XL
+ *           shape), g workgroups per instance share every row */
 int bxh_kernel_form(bxh_handle h);
 
 /* Solver fields x / pi / P (P in CSR element order, as `slv.P[e]`), and the
