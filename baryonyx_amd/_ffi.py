@@ -29,7 +29,7 @@ BXH_ERR_DEVICE = -4
 
 # every symbol include/bxh.h declares (tests check the library exports them)
 SYMBOLS = [
-    "bxh_last_error", "bxh_create", "bxh_destroy", "bxh_set_stream", "bxh_batch",
+    "bxh_last_error", "bxh_create", "bxh_create_device", "bxh_destroy", "bxh_set_stream", "bxh_batch",
     "bxh_nwords", "bxh_rmax", "bxh_kernel_form", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_set_pi", "bxh_get_pi",
     "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset", "bxh_reset_all",
     "bxh_order_create", "bxh_order_init", "bxh_order_init_masked", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
@@ -97,7 +97,8 @@ HIPCC_FLAGS = [
 def build(force: bool = False) -> str:
     """Compile csrc/bxh_device.hip for gfx950 into csrc/libbxh.so (in-tree, so
     it travels with the repository snapshot)."""
-    srcs = [os.path.join(CSRC, f) for f in ("bxh_device.hip", "bxh_kernels.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("bxh_device.hip", "bxh_kernels.hpp", "bxh_wide.hpp",
+                                          "bxh_wide_build.hpp")]
     srcs.append(os.path.join(_HERE, "..", "include", "bxh.h"))
     stale = force or not os.path.exists(LIB_PATH)
     if not stale:
@@ -122,6 +123,16 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
             )
+        # A process that also uses torch (device tensors handed to
+        # bxh_create_device, torch.distributed) must end up with ONE HIP runtime:
+        # torch's wheel bundles its own libamdhip64, and a library loaded before
+        # it binds the system one -- whose calls then fail with "no ROCm-capable
+        # device" once torch has initialised.  Loading torch first makes libbxh
+        # resolve to the runtime torch brought.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         # BXH_LIB: another build of the same C ABI (A/B timing of kernel variants)
         L = C.CDLL(os.environ.get("BXH_LIB") or LIB_PATH)
         L.bxh_last_error.restype = C.c_char_p
@@ -129,6 +140,7 @@ def lib():
             C.POINTER(BxhProblem), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
             C.POINTER(C.c_void_p),
         ]
+        L.bxh_create_device.argtypes = L.bxh_create.argtypes
         L.bxh_destroy.argtypes = [C.c_void_p]
         L.bxh_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         for nm in ("bxh_batch", "bxh_nwords", "bxh_rmax", "bxh_kernel_form"):
@@ -210,7 +222,37 @@ class DeviceBatch:
         h = C.c_void_p()
         _check(self.L.bxh_create(C.byref(pb), self.kind, float_type, int(self.maximize),
                                  self.batch, device, C.byref(h)))
+        self._finish(h, inst.m, inst.n, inst.nnz)
+
+    @classmethod
+    def on_device(cls, m, n, nnz, row_ptr, col, factor, cmin, cmax, cost, kind, maximize, batch,
+                  float_type=1, device=0, keep=None):
+        """bxh_create_device: the arguments row_ptr .. cost are DEVICE addresses
+        (ints, e.g. torch tensors' data_ptr(); factor may be 0 = all +1); `keep`
+        holds whatever owns that memory until the handle has copied it."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.inst = None
+        self.batch = int(batch)
+        self.kind = int(kind)
+        self.maximize = bool(maximize)
+        cast = lambda a, t: C.cast(C.c_void_p(int(a)), t) if a else None
+        pb = BxhProblem(
+            int(m), int(n), int(nnz),
+            cast(row_ptr, i32p), cast(col, i32p), cast(factor, i32p),
+            cast(cmin, i32p), cast(cmax, i32p), cast(cost, f64p),
+            0, None, None, None,
+        )
+        h = C.c_void_p()
+        _check(self.L.bxh_create_device(C.byref(pb), self.kind, float_type, int(self.maximize),
+                                        self.batch, device, C.byref(h)))
+        del keep
+        self._finish(h, m, n, nnz)
+        return self
+
+    def _finish(self, h, m, n, nnz):
         self.h = h
+        self.m, self.n, self.nnz = int(m), int(n), int(nnz)
         self.nwords = self.L.bxh_nwords(self.h)
         self.rmax = self.L.bxh_rmax(self.h)
         self.kernel_form = self.L.bxh_kernel_form(self.h)
@@ -241,6 +283,11 @@ class DeviceBatch:
         self._xall = w  # keep alive until the stream has consumed it
         _check(self.L.bxh_set_x_all(self.h, _p(w, u64p)))
 
+    def set_x_all_device(self, device_ptr, keep=None):
+        """x of every instance from DEVICE memory ([batch][nwords] u64), stream-ordered."""
+        self._xall = keep
+        _check(self.L.bxh_set_x_all(self.h, C.cast(C.c_void_p(int(device_ptr)), u64p)))
+
     def get_x(self, i):
         w = np.zeros(self.nwords, np.uint64)
         _check(self.L.bxh_get_x(self.h, i, _p(w, u64p)))
@@ -248,21 +295,21 @@ class DeviceBatch:
 
     def set_pi(self, i, v):
         v = np.ascontiguousarray(v, np.float64)
-        assert v.shape[0] == self.inst.m
+        assert v.shape[0] == self.m
         _check(self.L.bxh_set_pi(self.h, i, _p(v, f64p)))
 
     def get_pi(self, i):
-        v = np.zeros(self.inst.m, np.float64)
+        v = np.zeros(self.m, np.float64)
         _check(self.L.bxh_get_pi(self.h, i, _p(v, f64p)))
         return v
 
     def set_P(self, i, v):
         v = np.ascontiguousarray(v, np.float64)
-        assert v.shape[0] == self.inst.nnz
+        assert v.shape[0] == self.nnz
         _check(self.L.bxh_set_P(self.h, i, _p(v, f64p)))
 
     def get_P(self, i):
-        v = np.zeros(self.inst.nnz, np.float64)
+        v = np.zeros(self.nnz, np.float64)
         _check(self.L.bxh_get_P(self.h, i, _p(v, f64p)))
         return v
 
@@ -296,7 +343,7 @@ class DeviceBatch:
         return rem
 
     def violated(self, i):
-        rows = np.zeros(max(self.inst.m, self.inst.n), np.int32)
+        rows = np.zeros(max(self.m, self.n), np.int32)
         cnt = C.c_int32()
         _check(self.L.bxh_get_violated(self.h, i, _p(rows, i32p), C.byref(cnt)))
         return rows[: cnt.value].copy()
@@ -331,6 +378,6 @@ class DeviceBatch:
         return ms.value, n.value
 
     def row_bytes(self):
-        b = np.zeros(self.inst.m, np.float64)
+        b = np.zeros(self.m, np.float64)
         _check(self.L.bxh_row_bytes(self.h, _p(b, f64p)))
         return b

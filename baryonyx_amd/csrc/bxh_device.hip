@@ -7,6 +7,7 @@
 #include "../../include/bxh.h"
 #include "bxh_kernels.hpp"
 #include "bxh_wide.hpp"
+#include "bxh_wide_build.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -86,6 +87,8 @@ struct bxh_handle_s
     int sw_chain = 0, sw_prod = 0; // v2: staging waves of the chain / a producer
     int romax = 0;             // longest per-owner part of a row
     int wide_g = 0;            // wide kernel (version 4): workgroups per instance
+    bool device_built = false; // bxh_create_device: no host copy of the matrix exists
+    DevBuf<double> stage_d;    // bxh_set_P / bxh_get_P of a device-built handle: one chunk
     unsigned epoch = 0;        // sweep launches so far (tags of the row exchange)
 
     hipStream_t own_stream = nullptr;
@@ -1242,6 +1245,322 @@ bxh_create(const bxh_problem* pb,
     return BXH_OK;
 }
 
+// The same constructor for a matrix that already lives on the device (and may
+// be too large for any host loop: the XL shape has 2e9 elements): every array
+// of `pb` is a DEVICE pointer on `device`.  The CSC view, the bounds and the
+// accounting table are built by kernels (bxh_wide_build.hpp); the handle runs
+// the wide kernel.  01 / 101 solver kinds, linear objective.
+int
+bxh_create_device(const bxh_problem* pb,
+                  int kind,
+                  int float_type,
+                  int maximize,
+                  int batch,
+                  int device,
+                  bxh_handle* out)
+{
+    if (!pb || !out)
+        return fail(BXH_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (pb->m <= 0 || pb->n <= 0 || pb->nnz <= 0 || batch <= 0)
+        return fail(BXH_ERR_INVALID, "empty problem or batch");
+    if (!pb->row_ptr || !pb->col || !pb->cmin || !pb->cmax || !pb->cost)
+        return fail(BXH_ERR_INVALID, "null problem array");
+    if (kind < BXH_EQ_01 || kind > BXH_INEQ_101)
+        return fail(BXH_ERR_UNSUPPORTED, "bxh_create_device: 01 and 101 solver kinds only");
+    if (float_type != BXH_FLOAT && float_type != BXH_DOUBLE)
+        return fail(BXH_ERR_UNSUPPORTED, "only float and double exist on the device");
+    if (pb->n_quad != 0)
+        return fail(BXH_ERR_UNSUPPORTED, "bxh_create_device: linear objective only");
+    if (pb->nnz > 0x7fffffffLL)
+        return fail(BXH_ERR_UNSUPPORTED, "more than 2^31-1 elements");
+    hipError_t e0 = hipSetDevice(device);
+    if (e0 != hipSuccess)
+        return fail(BXH_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e0));
+
+    bxh_handle h = new (std::nothrow) bxh_handle_s;
+    if (!h)
+        return fail(BXH_ERR_OOM, "host allocation failed");
+    std::unique_ptr<bxh_handle_s> guard(h);
+    h->device = device;
+    h->kind = kind;
+    h->float_type = float_type;
+    h->maximize = maximize ? 1 : 0;
+    h->batch = batch;
+    h->m = pb->m;
+    h->n = pb->n;
+    h->nnz = static_cast<int>(pb->nnz);
+    h->nwords = pb->n / 64 + 1;
+    h->fsize = float_type == BXH_FLOAT ? 4 : 8;
+    h->device_built = true;
+    h->groups = 1;
+    const int m = h->m, n = h->n;
+    const size_t nnz = static_cast<size_t>(pb->nnz);
+    const bool pm1 = kind == BXH_EQ_101 || kind == BXH_INEQ_101;
+
+    HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    hipStream_t s = h->stream;
+
+    // ---- the CSR as given (the handle keeps its own copy) -------------------
+    HIP_TRY(h->row_ptr.alloc(static_cast<size_t>(m) + 1));
+    HIP_TRY(hipMemcpyAsync(h->row_ptr.p, pb->row_ptr, (static_cast<size_t>(m) + 1) * 4,
+                           hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h->row_col.alloc(nnz));
+    HIP_TRY(hipMemcpyAsync(h->row_col.p, pb->col, nnz * 4, hipMemcpyDeviceToDevice, s));
+    {
+        int ends[2] = { -1, -1 };
+        HIP_TRY(hipMemcpyAsync(&ends[0], pb->row_ptr, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&ends[1], pb->row_ptr + m, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (ends[0] != 0 || static_cast<long long>(ends[1]) != pb->nnz)
+            return fail(BXH_ERR_INVALID, "row_ptr does not span [0, nnz]");
+    }
+    DevBuf<int> scal; // [0] rmax, [1] error bits
+    HIP_TRY(scal.alloc(2));
+    HIP_TRY(hipMemsetAsync(scal.p, 0, 8, s));
+    hipLaunchKernelGGL(bxh::build::row_stats_kernel, dim3(2048), dim3(256), 0, s, h->row_ptr.p,
+                       h->row_col.p, pb->factor, m, n, pm1 ? 1 : 0, scal.p, scal.p + 1);
+    HIP_TRY(hipGetLastError());
+
+    // ---- column lengths: counts per (row block, column) ---------------------
+    const int nb = std::max(1, std::min(256, m / 16));
+    const int rpb = (m + nb - 1) / nb;
+    DevBuf<unsigned> cnt;
+    HIP_TRY(cnt.alloc(static_cast<size_t>(nb) * n));
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, static_cast<size_t>(nb) * n * 4, s));
+    hipLaunchKernelGGL(bxh::build::count_kernel, dim3(nb), dim3(1024), 0, s, h->row_ptr.p,
+                       h->row_col.p, m, n, rpb, cnt.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(h->col_len.alloc(static_cast<size_t>(n)));
+    hipLaunchKernelGGL(bxh::build::col_len_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cnt.p, nb,
+                       n, h->col_len.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<int> col_len(static_cast<size_t>(n));
+    HIP_TRY(hipMemcpyAsync(col_len.data(), h->col_len.p, static_cast<size_t>(n) * 4,
+                           hipMemcpyDeviceToHost, s));
+    int scal_h[2] = { 0, 0 };
+    HIP_TRY(hipMemcpyAsync(scal_h, scal.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (scal_h[1])
+        return fail(BXH_ERR_INVALID,
+                    "empty row, column index out of range or a coefficient this solver kind does not allow");
+    const int rmax = scal_h[0];
+    h->rmax = rmax;
+    // every column padded to a multiple of 16 entries (a whole number of
+    // 128-byte lines of fp64 P), as in bxh_create
+    std::vector<int2> cd(static_cast<size_t>(n));
+    long long at = 0;
+    int cmax = 0;
+    for (int j = 0; j != n; ++j) {
+        const int padded = std::max(16, (col_len[j] + 15) & ~15);
+        cd[j] = make_int2(static_cast<int>(at), padded);
+        at += padded;
+        cmax = std::max(cmax, col_len[j]);
+        if (at > 0x7fffffffLL)
+            return fail(BXH_ERR_UNSUPPORTED, "more than 2^31-1 padded elements");
+    }
+    const size_t nnzp = static_cast<size_t>(at);
+    h->nnzp = static_cast<int>(at);
+    HIP_TRY(h->col_desc.upload(cd));
+
+    // ---- the column view: rows ascending inside every column -----------------
+    hipLaunchKernelGGL(bxh::build::bases_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cnt.p, nb, n,
+                       h->col_desc.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(h->col_row.alloc(nnzp));
+    hipLaunchKernelGGL(bxh::build::fill_int_kernel, dim3(4096), dim3(256), 0, s, h->col_row.p, nnzp,
+                       m); // padding: row m (pi[m] == 0)
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(h->row_pos.alloc(nnz));
+    if (pm1)
+        HIP_TRY(h->fac_csr.alloc(nnz));
+    hipLaunchKernelGGL(bxh::build::fill_kernel, dim3(nb), dim3(1024), 0, s, h->row_ptr.p, h->row_col.p,
+                       pb->factor, m, n, rpb, cnt.p, h->col_row.p, h->row_pos.p,
+                       pm1 ? h->fac_csr.p : nullptr);
+    HIP_TRY(hipGetLastError());
+
+    // ---- bounds, accounting, costs -------------------------------------------
+    HIP_TRY(h->bmin.alloc(static_cast<size_t>(m)));
+    HIP_TRY(h->bmax.alloc(static_cast<size_t>(m)));
+    HIP_TRY(h->bneg.alloc(static_cast<size_t>(m)));
+    HIP_TRY(h->row_bytes.alloc(static_cast<size_t>(m)));
+    hipLaunchKernelGGL(bxh::build::bounds_kernel, dim3(2048), dim3(256), 0, s, h->row_ptr.p,
+                       h->row_col.p, pb->factor, pb->cmin, pb->cmax, h->col_len.p, m, kind,
+                       static_cast<double>(h->fsize), h->bmin.p, h->bmax.p, h->bneg.p, h->row_bytes.p,
+                       scal.p + 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(h->cost.alloc(static_cast<size_t>(n) * h->fsize));
+    if (float_type == BXH_FLOAT)
+        hipLaunchKernelGGL(bxh::build::cost_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s,
+                           pb->cost, reinterpret_cast<float*>(h->cost.p), n);
+    else
+        hipLaunchKernelGGL(bxh::build::cost_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, s,
+                           pb->cost, reinterpret_cast<double*>(h->cost.p), n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(scal_h, scal.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (scal_h[1] & 2)
+        return fail(BXH_ERR_INVALID, "an equalities solver needs min == max in every constraint");
+    if (scal_h[1])
+        return fail(BXH_ERR_INVALID, "constraint with min > max");
+    cnt.release(); // (1 GB at the XL shape: gone before the instances are allocated)
+    {
+        std::vector<unsigned> pw(1026);
+        unsigned long long v = 1;
+        for (size_t k = 0; k != pw.size(); ++k) {
+            pw[k] = static_cast<unsigned>(v);
+            v = v * 16807ull % 2147483647ull;
+        }
+        HIP_TRY(h->lcg_pow.upload(pw));
+    }
+
+    // ---- geometry of the wide kernel -----------------------------------------
+    int cus = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    int wide_g = std::max(1, std::min(cus / batch, rmax / 256));
+    if (const char* eg = std::getenv("BXH_GROUPS"))
+        if (eg[0] == 'w' && std::atoi(eg + 1) > 0)
+            wide_g = std::atoi(eg + 1);
+    if (batch * wide_g > cus || wide_g > 64 || wide_g < 1)
+        return fail(BXH_ERR_UNSUPPORTED,
+                    "the cooperating workgroups of all instances must be resident "
+                    "together (batch * workgroups per instance <= CUs)");
+    const int wide_chmax =
+      (((rmax + wide_g - 1) / wide_g) + bxh::WIDE_TILE - 1) & ~(bxh::WIDE_TILE - 1);
+    const bxh::WideLds wl = bxh::wide_lds(wide_g, wide_chmax, static_cast<int>(h->fsize));
+    if (wl.total > 160 * 1024)
+        return fail(BXH_ERR_UNSUPPORTED,
+                    "rows too long for the workgroups this batch leaves to an instance");
+    h->version = 4;
+    h->wide_g = wide_g;
+    h->threads = bxh::WIDE_T;
+    h->lds_bytes = static_cast<size_t>(wl.total);
+    if (std::getenv("BXH_DEBUG"))
+        std::fprintf(stderr, "bxh: device build m=%d n=%d nnz=%zu nnzp=%zu rmax=%d cmax=%d wide g=%d lds=%zu\n",
+                     m, n, nnz, nnzp, rmax, cmax, wide_g, h->lds_bytes);
+
+    // ---- per-instance state ------------------------------------------------------
+    const size_t B = static_cast<size_t>(batch), Gz = static_cast<size_t>(wide_g);
+    const size_t LC = static_cast<size_t>(m); // (row lists only: no pi_sign_change here)
+    h->lcap = static_cast<int>(LC);
+    HIP_TRY(h->P.alloc(B * nnzp * h->fsize));
+    HIP_TRY(hipMemsetAsync(h->P.p, 0, B * nnzp * h->fsize, s));
+    HIP_TRY(h->pi.alloc(B * m * h->fsize));
+    HIP_TRY(hipMemsetAsync(h->pi.p, 0, B * m * h->fsize, s));
+    HIP_TRY(h->rstale.alloc(B * (static_cast<size_t>(rmax) + 1) * h->fsize));
+    HIP_TRY(hipMemsetAsync(h->rstale.p, 0, B * (static_cast<size_t>(rmax) + 1) * h->fsize, s));
+    HIP_TRY(h->x.alloc(B * 2 * h->nwords));
+    HIP_TRY(hipMemsetAsync(h->x.p, 0, B * 2 * h->nwords * sizeof(unsigned), s));
+    HIP_TRY(h->vlist.alloc(B * LC));
+    HIP_TRY(h->vwork.alloc(B * Gz * LC));
+    HIP_TRY(h->vcount.alloc(B));
+    HIP_TRY(hipMemsetAsync(h->vcount.p, 0, B * sizeof(int), s));
+    HIP_TRY(h->mlist.alloc(B * LC));
+    HIP_TRY(h->mcount.alloc(B));
+    HIP_TRY(h->order_b.alloc(B));
+    HIP_TRY(hipMemsetAsync(h->order_b.p, 0, B * sizeof(int), s));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_order), B * sizeof(int), hipHostMallocDefault));
+    h->ostate.assign(B, 0);
+    HIP_TRY(h->status.alloc(B));
+    HIP_TRY(h->kappa.alloc(B));
+    HIP_TRY(h->active.alloc(B));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_status), B * sizeof(bxh::DevStatus),
+                          hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_kappa), B * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_active), B, hipHostMallocDefault));
+    {
+        std::vector<bxh::DevStatus> st(B);
+        for (auto& v : st) {
+            std::memset(&v, 0, sizeof v);
+            v.rng = 1;
+        }
+        HIP_TRY(hipMemcpy(h->status.p, st.data(), B * sizeof(bxh::DevStatus), hipMemcpyHostToDevice));
+    }
+    size_t hs = 1024;
+    while (hs < 4 * static_cast<size_t>(rmax))
+        hs <<= 1;
+    const size_t n2big = rmax > bxh::WIDE_SMALL ? static_cast<size_t>(bxh::next_pow2(rmax)) : 0;
+    HIP_TRY(h->piw.alloc(B * Gz * (static_cast<size_t>(m) + 1) * h->fsize));
+    HIP_TRY(h->whash.alloc(B * hs));
+    HIP_TRY(hipMemsetAsync(h->whash.p, 0, B * hs * sizeof(unsigned long long), s));
+    HIP_TRY(h->wrec.alloc(B * Gz * 8));
+    HIP_TRY(h->wcnt.alloc(4 * B + 1));
+    HIP_TRY(hipMemsetAsync(h->wcnt.p, 0, (4 * B + 1) * sizeof(unsigned), s));
+    HIP_TRY(h->vbuf.alloc(B * static_cast<size_t>(rmax)));
+    HIP_TRY(h->bkey.alloc(B * Gz * n2big));
+    HIP_TRY(h->bid.alloc(B * Gz * n2big));
+    HIP_TRY(h->vflag32.alloc(B * static_cast<size_t>(m)));
+    HIP_TRY(hipStreamSynchronize(s));
+
+    bxh::WideParams& wp = h->wp;
+    wp.G = wide_g;
+    wp.chmax = wide_chmax;
+    wp.hmask = static_cast<unsigned>(hs - 1);
+    wp.n2big = static_cast<int>(n2big);
+    wp.col_desc = h->col_desc.p;
+    wp.piw = h->piw.p;
+    wp.whash = h->whash.p;
+    wp.wrec = h->wrec.p;
+    wp.wcnt = h->wcnt.p;
+    wp.vbuf = h->vbuf.p;
+    wp.bkey = h->bkey.p;
+    wp.bid = h->bid.p;
+    wp.vflag32 = h->vflag32.p;
+    const int wlb = static_cast<int>(h->lds_bytes);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, wlb));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, wlb));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, wlb));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, wlb));
+
+    bxh::DevProblem& dp = h->dp;
+    dp.m = m;
+    dp.n = n;
+    dp.nnz = h->nnz;
+    dp.nnzp = h->nnzp;
+    dp.groups = 1;
+    dp.rmax = rmax;
+    dp.cmax = cmax;
+    dp.nwords = h->nwords;
+    dp.kind = kind;
+    dp.maximize = h->maximize;
+    dp.row_ptr = h->row_ptr.p;
+    dp.row_col = h->row_col.p;
+    dp.row_pos = h->row_pos.p;
+    dp.col_len = h->col_len.p;
+    dp.col_row = h->col_row.p;
+    dp.fac_csr = h->fac_csr.p;
+    dp.bmin = h->bmin.p;
+    dp.bmax = h->bmax.p;
+    dp.bneg = h->bneg.p;
+    dp.cost = h->cost.p;
+    dp.row_bytes = h->row_bytes.p;
+    dp.lcg_pow = h->lcg_pow.p;
+    bxh::DevState& ds = h->ds;
+    ds.P = h->P.p;
+    ds.pi = h->pi.p;
+    ds.x = h->x.p;
+    ds.rstale = h->rstale.p;
+    ds.vlist = h->vlist.p;
+    ds.vcount = h->vcount.p;
+    ds.status = h->status.p;
+    ds.vwork = h->vwork.p;
+    ds.lcap = h->lcap;
+    ds.mlist = h->mlist.p;
+    ds.mcount = h->mcount.p;
+
+    *out = guard.release();
+    return BXH_OK;
+}
+
 int
 bxh_destroy(bxh_handle h)
 {
@@ -1330,11 +1649,13 @@ bxh_set_x_all(bxh_handle h, const uint64_t* words)
     if (!h || !words)
         return fail(BXH_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    // pageable host memory: the copy is staged before this returns
+    // pageable host memory: the copy is staged before this returns; a device
+    // pointer (the XL bench builds its restart points on the device) is copied
+    // in stream order
     HIP_TRY(hipMemcpyAsync(h->x.p,
                            words,
                            static_cast<size_t>(h->batch) * h->nwords * 8,
-                           hipMemcpyHostToDevice,
+                           hipMemcpyDefault,
                            h->stream));
     return BXH_OK;
 }
@@ -1360,6 +1681,27 @@ bxh_set_P(bxh_handle h, int inst, const double* v)
 {
     if (int rc = check_inst(h, inst))
         return rc;
+    if (h->device_built) { // element order -> padded CSC order on the device, chunk by chunk
+        const size_t chunk = size_t{ 1 } << 24, total = static_cast<size_t>(h->nnz);
+        if (!h->stage_d.p)
+            HIP_TRY(h->stage_d.alloc(chunk));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (size_t e0 = 0; e0 < total; e0 += chunk) {
+            const size_t c = std::min(chunk, total - e0);
+            HIP_TRY(hipMemcpy(h->stage_d.p, v + e0, c * sizeof(double), hipMemcpyHostToDevice));
+            if (h->float_type == BXH_FLOAT)
+                hipLaunchKernelGGL(bxh::build::scatter_P_kernel<float>, dim3(1024), dim3(256), 0, h->stream,
+                                   reinterpret_cast<float*>(h->P.p) + static_cast<size_t>(inst) * h->nnzp,
+                                   h->row_pos.p, e0, c, h->stage_d.p);
+            else
+                hipLaunchKernelGGL(bxh::build::scatter_P_kernel<double>, dim3(1024), dim3(256), 0, h->stream,
+                                   reinterpret_cast<double*>(h->P.p) + static_cast<size_t>(inst) * h->nnzp,
+                                   h->row_pos.p, e0, c, h->stage_d.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        return BXH_OK;
+    }
     const size_t slice = static_cast<size_t>(h->nnzp), all = slice * h->groups;
     std::vector<double> csc(all, 0.0); // padding stays 0
     for (int e = 0; e != h->nnz; ++e)
@@ -1372,6 +1714,27 @@ bxh_get_P(bxh_handle h, int inst, double* v)
 {
     if (int rc = check_inst(h, inst))
         return rc;
+    if (h->device_built) {
+        const size_t chunk = size_t{ 1 } << 24, total = static_cast<size_t>(h->nnz);
+        if (!h->stage_d.p)
+            HIP_TRY(h->stage_d.alloc(chunk));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (size_t e0 = 0; e0 < total; e0 += chunk) {
+            const size_t c = std::min(chunk, total - e0);
+            if (h->float_type == BXH_FLOAT)
+                hipLaunchKernelGGL(bxh::build::gather_P_kernel<float>, dim3(1024), dim3(256), 0, h->stream,
+                                   reinterpret_cast<const float*>(h->P.p) + static_cast<size_t>(inst) * h->nnzp,
+                                   h->row_pos.p, e0, c, h->stage_d.p);
+            else
+                hipLaunchKernelGGL(bxh::build::gather_P_kernel<double>, dim3(1024), dim3(256), 0, h->stream,
+                                   reinterpret_cast<const double*>(h->P.p) + static_cast<size_t>(inst) * h->nnzp,
+                                   h->row_pos.p, e0, c, h->stage_d.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipMemcpy(v + e0, h->stage_d.p, c * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        return BXH_OK;
+    }
     const size_t slice = static_cast<size_t>(h->nnzp), all = slice * h->groups;
     std::vector<double> csc(all);
     if (int rc = get_vec(h, h->P.p + static_cast<size_t>(inst) * all * h->fsize, csc.data(), all))
@@ -1774,6 +2137,12 @@ bxh_row_bytes(bxh_handle h, double* bytes_m)
 {
     if (!h || !bytes_m)
         return fail(BXH_ERR_INVALID, "null argument");
+    if (h->device_built) { // computed by bounds_kernel
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpy(bytes_m, h->row_bytes.p, static_cast<size_t>(h->m) * sizeof(double),
+                          hipMemcpyDeviceToHost));
+        return BXH_OK;
+    }
     const double F = static_cast<double>(h->fsize);
     for (int k = 0; k != h->m; ++k) {
         const int rs = h->h_row_ptr[k], re = h->h_row_ptr[k + 1];

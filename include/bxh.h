@@ -134,6 +134,21 @@ int bxh_create(const bxh_problem* pb,
                int batch,
                int device,
                bxh_handle* out);
+/* The same constructors for a constraint matrix that is already resident on
+ * HIP device `device`: every pointer of `pb` is a DEVICE pointer.  The handle
+ * builds the column view of `sparse_matrix<int>` (lib/src/sparse-matrix.hpp:
+ * 86-186: stable by column) and the clamped bounds with kernels, once, shared
+ * by all `batch` instances -- the reference rebuilds them per worker thread
+ * (itm-optimizer-common.hpp:649-653); no host loop touches the elements
+ * (2e9 of them at the 100k x 1M shape).  Kinds BXH_EQ_01 .. BXH_INEQ_101,
+ * linear objective (n_quad == 0).  pb->factor may be NULL (all +1). */
+int bxh_create_device(const bxh_problem* pb_on_device,
+                      int kind,
+                      int float_type,
+                      int maximize,
+                      int batch,
+                      int device,
+                      bxh_handle* out);
 int bxh_destroy(bxh_handle h);
 
 /* Launch stream (a hipStream_t, e.g. torch's current stream); NULL = the
@@ -159,7 +174,7 @@ int bxh_set_x(bxh_handle h, int inst, const uint64_t* words);
 int bxh_get_x(bxh_handle h, int inst, uint64_t* words);
 /* x of every instance at once, [batch][nwords], stream-ordered (what the
  * restart loop does between two runs: reinit writes x,
- * itm-optimizer-common.hpp:660-663) */
+ * itm-optimizer-common.hpp:660-663); host or device memory */
 int bxh_set_x_all(bxh_handle h, const uint64_t* words_batch);
 int bxh_set_pi(bxh_handle h, int inst, const double* pi_m);
 int bxh_get_pi(bxh_handle h, int inst, double* pi_m);

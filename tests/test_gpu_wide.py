@@ -113,3 +113,86 @@ def test_xl_shaped_reduced_instance(oracle, bxh, float_type, groups, monkeypatch
             assert st["row_updates"][b] == s.row_updates, tag
         kappa = kappa + 0.05
     dev.close()
+
+
+DEVICE_BUILD_CASES = [
+    ("scp-int", lambda: synth.make_scp(300, 900, 0.05, "int", 101), 1, False, 0),
+    ("scp-real-f32-rev", lambda: synth.make_scp(200, 700, 0.08, "real", 102), 0, False, 1),
+    ("spp", lambda: synth.make_spp(120, 600, 0.05, "int", 103), 1, False, 0),
+    ("pm1-ineq-max", lambda: synth.make_pm1(150, 500, 0.06, "real", 104), 1, True, 2),
+    ("pm1-eq", lambda: synth.make_pm1(100, 400, 0.06, "int", 105, equalities=True), 1, False, 0),
+    ("long-columns", lambda: synth.make_scp(5000, 300, 0.1, "real", 106), 1, False, 0),
+]
+
+
+@pytest.mark.parametrize("groups", ["w1", "w3"])
+@pytest.mark.parametrize("case", DEVICE_BUILD_CASES, ids=[c[0] for c in DEVICE_BUILD_CASES])
+def test_device_built_matrix_matches_oracle(oracle, bxh, case, groups, monkeypatch):
+    """bxh_create_device: the CSR is handed over in device memory and the
+    column view / bounds are built by kernels (the only way in for the 2e9
+    elements of the XL shape) -- same results as the oracle, whose constructor
+    builds them on the host."""
+    import torch
+
+    from helpers import bits_equal, first_diff, random_x
+
+    monkeypatch.setenv("BXH_GROUPS", groups)
+    _, maker, float_type, maximize, order = case
+    inst = maker()
+    batch = 2
+    orcs = [oracle.Solver(inst, float_type=float_type, sort_mode=1, cost_norm=4, seed=700 + b,
+                          maximize=maximize) for b in range(batch)]
+    dev_t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in dict(
+        row_ptr=inst.row_ptr.astype(np.int32), col=inst.col.astype(np.int32),
+        factor=inst.factor.astype(np.int32), cmin=inst.cmin.astype(np.int32),
+        cmax=inst.cmax.astype(np.int32), cost=orcs[0].cost()).items()}
+    dev = bxh.DeviceBatch.on_device(
+        inst.m, inst.n, inst.nnz, dev_t["row_ptr"].data_ptr(), dev_t["col"].data_ptr(),
+        dev_t["factor"].data_ptr(), dev_t["cmin"].data_ptr(), dev_t["cmax"].data_ptr(),
+        dev_t["cost"].data_ptr(), inst.kind, maximize, batch, float_type=float_type, keep=dev_t)
+    del dev_t  # the handle owns copies
+    torch.cuda.empty_cache()
+    assert dev.kernel_form == 100 + int(groups[1:]) and dev.rmax == orcs[0].rmax
+    delta = orcs[0].compute_delta(0.5)
+    # bxh_row_bytes of a device-built handle == the host formula
+    F = 8 if float_type else 4
+    clen = np.bincount(inst.col, minlength=inst.n)
+    r = np.diff(inst.row_ptr)
+    want = (np.add.reduceat(clen[inst.col], inst.row_ptr[:-1]) * (4 + 2 * F) + r * (4 + 5 * F)
+            + 2 * F + ((r + 7) // 8) * 2)
+    assert np.array_equal(dev.row_bytes(), want.astype(np.float64))
+    for b, s in enumerate(orcs):
+        x0 = random_x(inst.n, 0.05, 31 + b)
+        s.set_x(x0)
+        dev.set_x(b, x0)
+        dev.set_rng(b, s.rng)
+        s.order_init(order)
+    rem = dev.order_init(order)
+    for b, s in enumerate(orcs):
+        assert rem[b] == len(s.violated())
+        assert np.array_equal(dev.violated(b), s.violated())
+    # P travels both ways through the device-side permutation
+    Pset = np.random.RandomState(5).standard_normal(inst.nnz)
+    if not float_type:
+        Pset = Pset.astype(np.float32).astype(np.float64)
+    for b, s in enumerate(orcs):
+        s.set_P(Pset * (b + 1))
+        dev.set_P(b, Pset * (b + 1))
+        assert bits_equal(dev.get_P(b), s.get_P())
+    kappa = np.array([0.02, 0.05])
+    for it in range(6):
+        push = it == 3
+        st = dev.sweep(kappa, delta, 0.5, is_push=push, obj_amp=5.0 if push else 0.0, order=order)
+        for b, s in enumerate(orcs):
+            rr = s.sweep(float(kappa[b]), delta, 0.5, is_push=push, obj_amp=5.0 if push else 0.0)
+            tag = f"sweep {it} inst {b}"
+            assert st["remaining"][b] == rr, tag
+            assert np.array_equal(dev.get_x(b), s.get_x()), tag + " x"
+            assert np.array_equal(dev.violated(b), s.violated()), tag + " violated"
+            pd, po = dev.get_pi(b), s.get_pi()
+            assert bits_equal(pd, po), f"{tag} pi first diff at {first_diff(pd, po)}"
+            Pd, Po = dev.get_P(b), s.get_P()
+            assert bits_equal(Pd, Po), f"{tag} P first diff at {first_diff(Pd, Po)}"
+            assert st["rng"][b] == s.rng, tag + " rng"
+        kappa = kappa + 0.03
+    dev.close()
