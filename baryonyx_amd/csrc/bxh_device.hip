@@ -865,7 +865,12 @@ bxh_create(const bxh_problem* pb,
     int wide_chmax = 0;
     if (wide_g) {
         wide_chmax = (((rmax + wide_g - 1) / wide_g) + bxh::WIDE_TILE - 1) & ~(bxh::WIDE_TILE - 1);
-        const bxh::WideLds wl = bxh::wide_lds(wide_g, wide_chmax, static_cast<int>(h->fsize));
+        // the pi window: the largest power of two that LDS still holds, all of pi if it fits
+        int ring = 1024;
+        while (ring < m + 1 && bxh::wide_lds(wide_g, wide_chmax, static_cast<int>(h->fsize), ring * 2).total <= lds_limit)
+            ring *= 2;
+        h->wp.ring = ring;
+        const bxh::WideLds wl = bxh::wide_lds(wide_g, wide_chmax, static_cast<int>(h->fsize), ring);
         if (wl.total > lds_limit)
             return fail(BXH_ERR_UNSUPPORTED,
                         "rows too long for the workgroups this batch leaves to an instance");
@@ -1074,6 +1079,8 @@ bxh_create(const bxh_problem* pb,
         wp.chmax = wide_chmax;
         wp.hmask = static_cast<unsigned>(hs - 1);
         wp.n2big = static_cast<int>(n2big);
+        wp.rows_per_piece = static_cast<float>(static_cast<double>(m) /
+                                               (static_cast<double>(nnzp) / 16.0 / static_cast<double>(n)));
         wp.col_desc = h->col_desc.p;
         wp.piw = h->piw.p;
         wp.whash = h->whash.p;
@@ -1432,7 +1439,11 @@ bxh_create_device(const bxh_problem* pb,
                     "together (batch * workgroups per instance <= CUs)");
     const int wide_chmax =
       (((rmax + wide_g - 1) / wide_g) + bxh::WIDE_TILE - 1) & ~(bxh::WIDE_TILE - 1);
-    const bxh::WideLds wl = bxh::wide_lds(wide_g, wide_chmax, static_cast<int>(h->fsize));
+    int ring = 1024; // the pi window: the largest power of two that LDS still holds
+    while (ring < m + 1 &&
+           bxh::wide_lds(wide_g, wide_chmax, static_cast<int>(h->fsize), ring * 2).total <= 160 * 1024)
+        ring *= 2;
+    const bxh::WideLds wl = bxh::wide_lds(wide_g, wide_chmax, static_cast<int>(h->fsize), ring);
     if (wl.total > 160 * 1024)
         return fail(BXH_ERR_UNSUPPORTED,
                     "rows too long for the workgroups this batch leaves to an instance");
@@ -1441,8 +1452,8 @@ bxh_create_device(const bxh_problem* pb,
     h->threads = bxh::WIDE_T;
     h->lds_bytes = static_cast<size_t>(wl.total);
     if (std::getenv("BXH_DEBUG"))
-        std::fprintf(stderr, "bxh: device build m=%d n=%d nnz=%zu nnzp=%zu rmax=%d cmax=%d wide g=%d lds=%zu\n",
-                     m, n, nnz, nnzp, rmax, cmax, wide_g, h->lds_bytes);
+        std::fprintf(stderr, "bxh: device build m=%d n=%d nnz=%zu nnzp=%zu rmax=%d cmax=%d wide g=%d lds=%zu ring=%d\n",
+                     m, n, nnz, nnzp, rmax, cmax, wide_g, h->lds_bytes, ring);
 
     // ---- per-instance state ------------------------------------------------------
     const size_t B = static_cast<size_t>(batch), Gz = static_cast<size_t>(wide_g);
@@ -1502,6 +1513,9 @@ bxh_create_device(const bxh_problem* pb,
     wp.chmax = wide_chmax;
     wp.hmask = static_cast<unsigned>(hs - 1);
     wp.n2big = static_cast<int>(n2big);
+    wp.ring = ring;
+    wp.rows_per_piece = static_cast<float>(static_cast<double>(m) /
+                                           (static_cast<double>(nnzp) / 16.0 / static_cast<double>(n)));
     wp.col_desc = h->col_desc.p;
     wp.piw = h->piw.p;
     wp.whash = h->whash.p;

@@ -59,6 +59,8 @@ struct WideParams
     int chmax;                 // longest part of a row one workgroup takes (multiple of 32)
     unsigned hmask;            // slots of the tie table - 1
     int n2big;                 // next_pow2(rmax) when rmax > WIDE_SMALL, else 0
+    int ring;                  // pi entries of the LDS window (a power of two)
+    float rows_per_piece;      // m / (mean 16-entry pieces of a column): the window's pace
     const int2* col_desc;      // [n] {first padded CSC slot, padded length}
     void* piw;                 // [batch][G][m+1] Float: pi, one copy per workgroup
     unsigned long long* whash; // [batch][hmask+1] keys of the row (0 = empty)
@@ -78,11 +80,12 @@ wide_stage_bytes(int fsize)
 
 struct WideLds
 {
-    int off_misc, off_part, off_rec, off_val, off_pown, off_hslot, off_union, union_bytes, total;
+    int off_misc, off_part, off_rec, off_val, off_pown, off_hslot, off_union, union_bytes, off_ring,
+      total;
 };
 
 __host__ __device__ inline WideLds
-wide_lds(int G, int chmax, int fsize)
+wide_lds(int G, int chmax, int fsize, int ring)
 {
     auto al = [](int v) { return (v + 15) & ~15; };
     WideLds p;
@@ -102,30 +105,92 @@ wide_lds(int G, int chmax, int fsize)
     p.off_union = o;
     p.union_bytes = (WIDE_T / 64) * wide_stage_bytes(fsize);
     o = al(o + p.union_bytes);
+    p.off_ring = o; // pi of the rows [lo, lo + ring) by row % ring, + one zero entry (padding)
+    o = al(o + (ring + 1) * fsize);
     p.total = o;
     return p;
 }
 
-typedef unsigned v4u_w __attribute__((ext_vector_type(4)));
+// ---------------------------------------------------------------------------
+// The streaming loads of the column sums.  They are asynchronous and must stay
+// in flight across other code (a piece ahead), which no compiler-visible
+// register may do: hipcc knows nothing of a load issued from asm and is free to
+// copy its destination before the data has landed (it did: v_mov of all sixteen
+// gather destinations in front of the wait).  So the loads land in ACCUMULATOR
+// registers named literally -- on gfx950 AGPRs come out of the same file as the
+// VGPRs, a kernel without MFMA never touches them otherwise, and listing them as
+// clobbers makes the kernel descriptor allocate them -- and are moved on by the
+// very asm statement that waits for them:
+//   a[0:23]   staging loads of one 16-entry piece: P (a[0:15] fp64 / a[0:7] fp32:
+//             device-scope sc1 loads, P is written by the other workgroups of
+//             the instance) and row indices (a[16:23], read-only data),
+//             ds_write_b128 straight from the AGPRs.
+#define BXH_WIDE_STAGE_CLOBBER                                                                     \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", \
+      "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23"
 
-// 16-byte loads with a 64-bit address.  P is written by other workgroups of
-// the instance during the launch: device-scope (sc1) loads, never served from
-// this CU's L1.  The row indices are read-only.  hipcc does not count loads
-// issued from asm: the s_waitcnt statement behind them names every destination.
-__device__ inline v4u_w
-wide_load_sc1(const void* p)
+template<typename Float>
+struct WideAsm;
+
+template<>
+struct WideAsm<double>
 {
-    v4u_w r;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
-    return r;
-}
-__device__ inline v4u_w
-wide_load(const void* p)
+    // staging loads of one piece: 4 x 16 B of P (8 columns each), 2 x 16 B of indices
+    __device__ static inline void issue(const char* p0, const char* p1, const char* p2,
+                                        const char* p3, const char* i0, const char* i1)
+    {
+        asm volatile("global_load_dwordx4 a[0:3], %0, off sc1\n"
+                     "global_load_dwordx4 a[4:7], %1, off sc1\n"
+                     "global_load_dwordx4 a[8:11], %2, off sc1\n"
+                     "global_load_dwordx4 a[12:15], %3, off sc1\n"
+                     "global_load_dwordx4 a[16:19], %4, off\n"
+                     "global_load_dwordx4 a[20:23], %5, off\n"
+                     :
+                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(i0), "v"(i1)
+                     : "memory", BXH_WIDE_STAGE_CLOBBER);
+    }
+    // ... have landed (nothing else of this wave is in flight): into the wave's LDS slots
+    __device__ static inline void land(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(0)\n"
+                     "ds_write_b128 %0, a[0:3]\n"
+                     "ds_write_b128 %0, a[4:7] offset:1152\n"
+                     "ds_write_b128 %0, a[8:11] offset:2304\n"
+                     "ds_write_b128 %0, a[12:15] offset:3456\n"
+                     "ds_write_b128 %1, a[16:19]\n"
+                     "ds_write_b128 %1, a[20:23] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", BXH_WIDE_STAGE_CLOBBER);
+    }
+};
+
+template<>
+struct WideAsm<float>
 {
-    v4u_w r;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-    return r;
-}
+    __device__ static inline void issue(const char* p0, const char* p1, const char*, const char*,
+                                        const char* i0, const char* i1)
+    {
+        asm volatile("global_load_dwordx4 a[0:3], %0, off sc1\n"
+                     "global_load_dwordx4 a[4:7], %1, off sc1\n"
+                     "global_load_dwordx4 a[16:19], %2, off\n"
+                     "global_load_dwordx4 a[20:23], %3, off\n"
+                     :
+                     : "v"(p0), "v"(p1), "v"(i0), "v"(i1)
+                     : "memory", BXH_WIDE_STAGE_CLOBBER);
+    }
+    __device__ static inline void land(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(0)\n"
+                     "ds_write_b128 %0, a[0:3]\n"
+                     "ds_write_b128 %0, a[4:7] offset:1280\n"
+                     "ds_write_b128 %1, a[16:19]\n"
+                     "ds_write_b128 %1, a[20:23] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", BXH_WIDE_STAGE_CLOBBER);
+    }
+};
 
 // Insert a key of the row into the instance's table (open addressing, one
 // 64-bit compare-and-swap per probe, executed at the memory side: coherent for
@@ -180,8 +245,8 @@ wide_sync(unsigned* cnt, unsigned target, unsigned* err, int* dead_s)
 
 enum
 {
-    WM_DEAD = 96,  // a partner timed out: leave the sweep
-    WM_NSLOW = 97
+    WM_DEAD = 96, // a partner timed out: leave the sweep
+    WM_TNP = 97   // longest column (in pieces) of this workgroup's part of the row
 };
 
 // One sweep of every instance: compute_order::run / push_and_run
@@ -210,7 +275,8 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
     const int tid = threadIdx.x;
     constexpr int T = WIDE_T;
     const int lane = tid & 63, wave = tid >> 6;
-    const WideLds lp = wide_lds(G, wp.chmax, (int)sizeof(Float));
+    const WideLds lp = wide_lds(G, wp.chmax, (int)sizeof(Float), wp.ring);
+    Float* ring_s = (Float*)(smem + lp.off_ring);
     int* misc_s = (int*)(smem + lp.off_misc);
     Float* d_s = (Float*)(misc_s + MS_D);
     unsigned long long* part_s = (unsigned long long*)(smem + lp.off_part);
@@ -274,6 +340,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
     if (tid == 0) {
         misc_s[MS_PICH] = 0;
         misc_s[WM_DEAD] = 0;
+        ring_s[wp.ring] = 0; // what the padding of a column reads
     }
     __syncthreads();
     if (tid == 0) {
@@ -286,6 +353,9 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
 
     unsigned nslow = 0;
     bool dead = false;
+    // byte address of the dynamic LDS segment in the LDS address space (ds_write from asm)
+    const unsigned lds_base =
+      (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     unsigned char* stg_p = uni + (size_t)wave * wide_stage_bytes((int)sizeof(Float));
     unsigned char* stg_i = stg_p + WIDE_TILE * Geo::PSLOT;
 
@@ -314,12 +384,39 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
         __syncthreads();
 
         // ---- compute_reduced_costs: this workgroup's columns, 32 per wave ---
+        // The eight waves take eight tiles at a time (a tile set) and walk them
+        // in step, piece by piece: the rows inside a column ascend, so at piece
+        // t every column of the set is near row (t + 1/2) * rows_per_piece, and
+        // a window of `ring` pi entries in LDS, moved along by all waves
+        // together, serves nearly every entry (the others: a gather from the
+        // workgroup's copy in global memory).
         const int ntile = (cnt + WIDE_TILE - 1) / WIDE_TILE;
-        for (int tile = wave; tile < ntile; tile += T / 64) {
+        const int nset = (ntile + T / 64 - 1) / (T / 64);
+        // longest column of this workgroup's part, in pieces (uniform over the workgroup)
+        if (tid == 0)
+            misc_s[WM_TNP] = 0;
+        __syncthreads();
+        {
+            int mynp = 0;
+            for (int l = tid; l < cnt; l += T)
+                mynp = max(mynp, wp.col_desc[pb.row_col[rs + start + l]].y >> 4);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                mynp = max(mynp, __shfl_xor(mynp, o, 64));
+            if (lane == 0 && mynp > 0)
+                atomicMax(&misc_s[WM_TNP], mynp);
+        }
+        __syncthreads();
+        const int tnp_row = misc_s[WM_TNP];
+        const int RB = wp.ring >> 1;                 // the window moves by half its length
+        const int nblk = (m + RB - 1) / RB;          // blocks of RB rows
+        const unsigned rmask = (unsigned)wp.ring - 1u;
+        for (int set = 0; set < nset; ++set) {
+            const int tile = set * (T / 64) + wave;
             const int c = lane & 31;
             const bool prole = lane < 32;
             const int l = tile * WIDE_TILE + c;
-            const bool valid = l < cnt;
+            const bool valid = tile < ntile && l < cnt;
             int cs = 0, np = 0;
             Float cj = 0;
             bool negf = false;
@@ -337,6 +434,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1)
                 tnp = max(tnp, __shfl_xor(tnp, o, 64));
+            tnp = __builtin_amdgcn_readfirstlane(tnp); // (uniform: scalar loop control)
             // the columns this lane loads for: their first slot and piece count
             const char* pbase[Geo::PL];
             int pnp[Geo::PL];
@@ -357,55 +455,91 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 ibase[i] = (const char*)pb.col_row + (size_t)ccs * 4 + (lane & 3) * 16;
             }
             Float sum = 0; // lanes 0-31: sum_a_p of column c, lanes 32-63: sum_a_pi
-            for (int piece = 0; piece < tnp; ++piece) {
-                v4u_w pv[Geo::PL], iv[2];
-#pragma unroll
-                for (int i = 0; i < Geo::PL; ++i)
-                    pv[i] = wide_load_sc1(pbase[i] +
-                                          (size_t)min(piece, pnp[i] - 1) * (16 * sizeof(Float)));
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    iv[i] = wide_load(ibase[i] + (size_t)min(piece, inp[i] - 1) * 64);
-                if constexpr (Geo::PL == 4)
-                    asm volatile("s_waitcnt vmcnt(0)"
-                                 : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(iv[0]),
-                                   "+v"(iv[1])::"memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(0)"
-                                 : "+v"(pv[0]), "+v"(pv[1]), "+v"(iv[0]), "+v"(iv[1])::"memory");
-#pragma unroll
-                for (int i = 0; i < Geo::PL; ++i)
-                    *(v4u_w*)(stg_p + (i * Geo::PCOLS + lane / Geo::PPARTS) * Geo::PSLOT +
-                              (lane % Geo::PPARTS) * 16) = pv[i];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    *(v4u_w*)(stg_i + (i * 16 + (lane >> 2)) * WIDE_ISLOT + (lane & 3) * 16) = iv[i];
+            // Software pipeline, one piece ahead: the staging loads of piece t + 1
+            // are issued as soon as piece t has left the accumulator registers
+            // and stay in flight while piece t is summed.
+            auto issue = [&](int piece) {
+                const char* a0 = pbase[0] + (size_t)min(piece, pnp[0] - 1) * (16 * sizeof(Float));
+                const char* a1 = pbase[1] + (size_t)min(piece, pnp[1] - 1) * (16 * sizeof(Float));
+                const char* a2 = pbase[Geo::PL - 2] +
+                                 (size_t)min(piece, pnp[Geo::PL - 2] - 1) * (16 * sizeof(Float));
+                const char* a3 = pbase[Geo::PL - 1] +
+                                 (size_t)min(piece, pnp[Geo::PL - 1] - 1) * (16 * sizeof(Float));
+                const char* b0 = ibase[0] + (size_t)min(piece, inp[0] - 1) * 64;
+                const char* b1 = ibase[1] + (size_t)min(piece, inp[1] - 1) * 64;
+                WideAsm<Float>::issue(a0, a1, a2, a3, b0, b1);
+            };
+            const unsigned lds_p = lds_base + (unsigned)(stg_p - smem) +
+                                   (unsigned)((lane / Geo::PPARTS) * Geo::PSLOT + (lane % Geo::PPARTS) * 16);
+            const unsigned lds_i = lds_base + (unsigned)(stg_i - smem) +
+                                   (unsigned)((lane >> 2) * WIDE_ISLOT + (lane & 3) * 16);
+            if (tnp > 0)
+                issue(0);
+            int cur_b0 = -2; // first block of the window in LDS
+            for (int piece = 0; piece < tnp_row; ++piece) {
+                // ---- the window: blocks b0 and b0 + 1, centred on this piece's rows
+                {
+                    const float centre = ((float)piece + 0.5f) * wp.rows_per_piece;
+                    int b0 = (int)(centre / (float)RB - 0.5f);
+                    b0 = max(0, min(b0, nblk - 2));
+                    if (b0 != cur_b0) {
+                        __syncthreads(); // every wave is done with the blocks that go
+                        for (int bb = (b0 == cur_b0 + 1 ? b0 + 1 : b0); bb <= b0 + 1; ++bb)
+                            for (int i = tid; i < RB; i += T) {
+                                const int rr = bb * RB + i;
+                                ring_s[(unsigned)rr & rmask] = rr < m ? piw[rr] : (Float)0;
+                            }
+                        cur_b0 = b0;
+                        __syncthreads();
+                    }
+                }
+                if (piece >= tnp)
+                    continue; // (this wave's tile is shorter: it only keeps the barriers)
+                const int lo = cur_b0 * RB;
+                WideAsm<Float>::land(lds_p, lds_i);
                 // (the slots are this wave's own: no barrier, but the compiler must
                 // keep the other lanes' writes in front of this lane's reads)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (piece < np) {
-                    const int* ip = (const int*)(stg_i + c * WIDE_ISLOT);
-                    if (prole) {
+                const bool act = piece < np;
+                const int* ip = (const int*)(stg_i + c * WIDE_ISLOT);
+                int ri[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    ri[t] = ip[t];
+                if (piece + 1 < tnp)
+                    issue(piece + 1);
+                if (prole) {
+                    if (act) {
                         const Float* sp = (const Float*)(stg_p + c * Geo::PSLOT);
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
                             const Float p = sp[t];
                             if (PM1) {
-                                const Float fa = (ip[t] & 0x40000000) ? (Float)-1 : (Float)1;
+                                const Float fa = (ri[t] & 0x40000000) ? (Float)-1 : (Float)1;
                                 sum += fa * p;
                             } else
                                 sum += p;
                         }
-                    } else {
-                        Float piv[16];
-                        int ri[16];
+                    }
+                } else {
+                    Float piv[16];
+                    unsigned out = 0; // entries whose row is outside the window
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int rr = ri[t] & 0x3fffffff;
+                        const bool pad = rr == m;
+                        const bool in = pad || (unsigned)(rr - lo) < (unsigned)wp.ring;
+                        piv[t] = ring_s[pad ? (unsigned)wp.ring : ((unsigned)rr & rmask)];
+                        out |= (in || !act) ? 0u : (1u << t);
+                    }
+                    if (out) { // (rare: a column far ahead of or behind the others)
 #pragma unroll
                         for (int t = 0; t < 16; ++t)
-                            ri[t] = ip[t];
-#pragma unroll
-                        for (int t = 0; t < 16; ++t)
-                            piv[t] = piw[ri[t] & 0x3fffffff];
+                            if (out & (1u << t))
+                                piv[t] = piw[ri[t] & 0x3fffffff];
+                    }
+                    if (act) {
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
                             if (PM1) {

@@ -209,6 +209,65 @@ bxc_merged(const char* path,
     return 0;
 }
 
+// baryonyx::optimize on a file with the recorder's final state (tests): the
+// population best first ([population] entries, x as [population][nwords] 64-bit
+// blocks of the PREPROCESSED variables), every worker's engine and restart count.
+BX_EXPORT int
+bxc_optimize_trace(const char* path, const bxc_params* p, bxc_result* out, int population, int nwords,
+                   int* pop_remaining, double* pop_value, unsigned long long* pop_hash,
+                   unsigned long long* pop_x, unsigned* worker_rng, long long* worker_calls,
+                   long long* rounds, char* err, int errlen)
+{
+    std::memset(out, 0, sizeof *out);
+    try {
+        auto ctx = make_ctx(p);
+        optimize_trace t;
+        ctx->trace = &t;
+        const raw_problem pb = make_problem(ctx, path);
+        if (!pb) {
+            std::snprintf(err, static_cast<size_t>(errlen), "parse error %d", static_cast<int>(pb.status));
+            return -1;
+        }
+        const result r = optimize(ctx, pb);
+        out->status = static_cast<int>(r.status);
+        out->remaining_constraints = r.remaining_constraints;
+        out->variables = r.variables;
+        out->constraints = r.constraints;
+        out->n_solutions = static_cast<int>(r.solutions.size());
+        out->loop = r.loop;
+        out->duration = r.duration;
+        if (!r.solutions.empty())
+            out->value = r.solutions.front().value;
+        out->valid = is_valid_solution(pb, r) ? 1 : 0;
+        if (r && !r.solutions.empty())
+            out->recomputed_value = compute_solution(pb, r);
+        if (static_cast<int>(t.pop_value.size()) != population ||
+            (population > 0 && static_cast<int>(t.pop_x[0].size()) != nwords)) {
+            std::snprintf(err, static_cast<size_t>(errlen), "trace shape: population %zu, words %zu",
+                          t.pop_value.size(), t.pop_x.empty() ? size_t{ 0 } : t.pop_x[0].size());
+            return -4;
+        }
+        for (int i = 0; i != population; ++i) {
+            pop_remaining[i] = t.pop_remaining[i];
+            pop_value[i] = t.pop_value[i];
+            pop_hash[i] = t.pop_hash[i];
+            std::copy(t.pop_x[i].begin(), t.pop_x[i].end(), pop_x + static_cast<size_t>(i) * nwords);
+        }
+        for (size_t b = 0; b != t.worker_rng.size(); ++b) {
+            worker_rng[b] = t.worker_rng[b];
+            worker_calls[b] = t.worker_calls[b];
+        }
+        *rounds = t.rounds;
+        return 0;
+    } catch (const solver_failure& e) {
+        std::snprintf(err, static_cast<size_t>(errlen), "solver_failure %d", static_cast<int>(e.failure()));
+        return -2;
+    } catch (const std::exception& e) {
+        std::snprintf(err, static_cast<size_t>(errlen), "%s", e.what());
+        return -3;
+    }
+}
+
 // baryonyx::solve (mode 0) or baryonyx::optimize (mode 1) on a file.
 BX_EXPORT int
 bxc_run(const char* path, int mode, const bxc_params* p, bxc_result* out, signed char* x_out, char* err, int errlen)

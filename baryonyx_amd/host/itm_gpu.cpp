@@ -437,6 +437,20 @@ struct device_batch
         a.active = active.data();
         check(bxh_sweep(h, &a, status.data()));
     }
+    // the same, without waiting for the outcome (sync() fetches it)
+    void sweep_async(double delta, double theta, bool push, double obj_amp, int order)
+    {
+        bxh_sweep_args a{};
+        a.kappa = kappa.data();
+        a.delta = delta;
+        a.theta = theta;
+        a.obj_amp = obj_amp;
+        a.is_push = push ? 1 : 0;
+        a.order = order;
+        a.active = active.data();
+        check(bxh_sweep_async(h, &a));
+    }
+    void sync() { check(bxh_status_sync(h, status.data())); }
 };
 
 int
@@ -1004,6 +1018,7 @@ optimize_problem(const context& ctx, const problem& pb)
     // one compute_order per worker, constructed once (itm-optimizer-common.hpp:655)
     slv.order_create(order);
     std::vector<std::uint8_t> init_mask(static_cast<size_t>(workers), 0);
+    std::vector<std::uint8_t> swept(static_cast<size_t>(workers), 0);
 
     long sweeps = 0;
     for (;;) {
@@ -1035,77 +1050,82 @@ optimize_problem(const context& ctx, const problem& pb)
             slv.order_init(order, &init_mask); // compute.init of the restarted workers only
 
         // -- one sweep of everybody: run() for MAIN / PUSH_ITER, push_and_run
-        //    for PUSH (two launches when both kinds are present) -------------
+        //    for PUSH (two launches when both kinds are present), then the
+        //    bookkeeping of every worker in id order -------------------------
+        std::fill(swept.begin(), swept.end(), std::uint8_t{ 0 });
         for (int pass = 0; pass != 2; ++pass) {
             const bool push = pass == 1;
             bool any = false;
             for (int b = 0; b != workers; ++b) {
                 const bool mine = (wk[b].phase == PH_PUSH) == push;
                 slv.active[b] = mine ? 1 : 0;
+                if (mine)
+                    swept[static_cast<size_t>(b)] = 1;
                 any = any || mine;
                 slv.kappa[b] = static_cast<double>(push ? pushing_k_factor : wk[b].kappa);
             }
             if (!any)
                 continue;
-            slv.sweep(static_cast<double>(delta), static_cast<double>(theta), push,
-                      push ? static_cast<double>(pushing_objective_amplifier) : 0.0, order);
-            for (int b = 0; b != workers; ++b) {
-                if (!slv.active[b])
-                    continue;
-                worker& w = wk[b];
-                const int remaining = slv.status[b].remaining;
-                set_engine_state(lctx[b].rng, slv.status[b].rng);
-                auto update = [&](long loop) {
-                    slv.get_x(b, w.x);
-                    best_recorder.try_update(lctx[b], w.x, cost.results(w.x, cost_constant), loop);
-                };
-                switch (w.phase) {
-                case PH_MAIN: // :668-700
-                    if (remaining == 0) {
-                        update(w.i);
-                        w.best_remaining = 0;
-                        w.push = 0;
-                        w.phase = p.pushes_limit > 0 ? PH_PUSH : PH_REINIT;
-                        break;
-                    }
-                    w.best_remaining = std::min(remaining, w.best_remaining);
-                    if (w.i > w_limit)
-                        kappa_inc(w, remaining);
-                    ++w.i;
-                    if (w.kappa > kappa_max || w.i == p.limit) {
-                        slv.get_x(b, w.x);
-                        best_recorder.try_advance(lctx[b], w.x, w.best_remaining, p.limit);
-                        w.phase = PH_REINIT;
-                    }
-                    break;
-                case PH_PUSH: // :705-723
-                    if (remaining == 0)
-                        update(-w.push * p.pushing_iteration_limit - 1);
-                    w.kappa = w.kappa_start;
-                    w.iter = 0;
-                    if (p.pushing_iteration_limit > 0)
-                        w.phase = PH_PUSH_ITER;
-                    else
-                        next_push(w);
-                    break;
-                default: // PH_PUSH_ITER, :724-749
-                    if (remaining == 0) {
-                        update(-w.push * p.pushing_iteration_limit - w.iter - 1);
-                        next_push(w);
-                        break;
-                    }
-                    if (w.iter > p.w)
-                        kappa_inc(w, remaining);
-                    ++w.iter;
-                    if (w.kappa > kappa_max || w.iter >= p.pushing_iteration_limit)
-                        next_push(w);
+            slv.sweep_async(static_cast<double>(delta), static_cast<double>(theta), push,
+                            push ? static_cast<double>(pushing_objective_amplifier) : 0.0, order);
+        }
+        slv.sync();
+        for (int b = 0; b != workers; ++b) {
+            if (!swept[static_cast<size_t>(b)])
+                continue;
+            worker& w = wk[b];
+            const int remaining = slv.status[b].remaining;
+            set_engine_state(lctx[b].rng, slv.status[b].rng);
+            auto update = [&](long loop) {
+                slv.get_x(b, w.x);
+                best_recorder.try_update(lctx[b], w.x, cost.results(w.x, cost_constant), loop);
+            };
+            switch (w.phase) {
+            case PH_MAIN: // :668-700
+                if (remaining == 0) {
+                    update(w.i);
+                    w.best_remaining = 0;
+                    w.push = 0;
+                    w.phase = p.pushes_limit > 0 ? PH_PUSH : PH_REINIT;
                     break;
                 }
-                // the host engine may have advanced (try_update): the device
-                // copy is refreshed at the next reinit or right here
-                if (engine_state(lctx[b].rng) != slv.status[b].rng)
-                    slv.set_rng(b, lctx[b].rng);
+                w.best_remaining = std::min(remaining, w.best_remaining);
+                if (w.i > w_limit)
+                    kappa_inc(w, remaining);
+                ++w.i;
+                if (w.kappa > kappa_max || w.i == p.limit) {
+                    slv.get_x(b, w.x);
+                    best_recorder.try_advance(lctx[b], w.x, w.best_remaining, p.limit);
+                    w.phase = PH_REINIT;
+                }
+                break;
+            case PH_PUSH: // :705-723
+                if (remaining == 0)
+                    update(-w.push * p.pushing_iteration_limit - 1);
+                w.kappa = w.kappa_start;
+                w.iter = 0;
+                if (p.pushing_iteration_limit > 0)
+                    w.phase = PH_PUSH_ITER;
+                else
+                    next_push(w);
+                break;
+            default: // PH_PUSH_ITER, :724-749
+                if (remaining == 0) {
+                    update(-w.push * p.pushing_iteration_limit - w.iter - 1);
+                    next_push(w);
+                    break;
+                }
+                if (w.iter > p.w)
+                    kappa_inc(w, remaining);
+                ++w.iter;
+                if (w.kappa > kappa_max || w.iter >= p.pushing_iteration_limit)
+                    next_push(w);
+                break;
             }
+            // the host engine may have advanced (try_update): the device
+            // copy is refreshed at the next reinit or right here
+            if (engine_state(lctx[b].rng) != slv.status[b].rng)
+                slv.set_rng(b, lctx[b].rng);
         }
         ++sweeps;
 
@@ -1119,6 +1139,21 @@ optimize_problem(const context& ctx, const problem& pb)
         }
     }
 
+    if (ctx.trace) {
+        optimize_trace& t = *ctx.trace;
+        t.rounds = sweeps;
+        for (int i = 0; i != best_recorder.size; ++i) {
+            const auto& e = best_recorder.best(i);
+            t.pop_remaining.push_back(e.remaining_constraints);
+            t.pop_value.push_back(e.value);
+            t.pop_hash.push_back(static_cast<std::uint64_t>(e.hash));
+            t.pop_x.emplace_back(e.x.w.begin(), e.x.w.end());
+        }
+        for (int b = 0; b != workers; ++b) {
+            t.worker_rng.push_back(engine_state(lctx[b].rng));
+            t.worker_calls.push_back(wk[b].calls);
+        }
+    }
     fill_result(r, pb, variables, static_cast<int>(constraints.size()));
     const auto& first = best_recorder.best(0);
     r.status = first.is_solution() ? result_status::success : result_status::time_limit_reached;

@@ -5,6 +5,7 @@
 #ifndef BARYONYX_AMD_HOST_PRIVATE_HPP
 #define BARYONYX_AMD_HOST_PRIVATE_HPP
 
+#include <cstdint>
 #include <baryonyx/core>
 
 #include <chrono>
@@ -36,6 +37,20 @@ struct context
     int device = 0; // HIP device of the batch (context_set_parameters("device"))
     long sweep_budget = 0; // > 0: optimize() also stops after that many
                            // lock-step sweeps (context_set_parameters("sweep-budget"))
+    struct optimize_trace* trace = nullptr; // tests: the recorder's final state
+};
+
+// What optimize() leaves behind for the parity tests (population best first,
+// every worker's engine and restart count): filled when context::trace is set.
+struct optimize_trace
+{
+    std::vector<int> pop_remaining;
+    std::vector<double> pop_value;
+    std::vector<std::uint64_t> pop_hash;
+    std::vector<std::vector<std::uint64_t>> pop_x;
+    std::vector<unsigned> worker_rng;
+    std::vector<long> worker_calls;
+    long rounds = 0;
 };
 
 template<typename... Args>

@@ -80,6 +80,10 @@ def lib():
                                      C.POINTER(PreprocessInfo), dp, ip, dp, ip, ip]
         L.bxc_run.argtypes = [C.c_char_p, C.c_int, C.POINTER(Params), C.POINTER(Result),
                               C.POINTER(C.c_byte), C.c_char_p, C.c_int]
+        ullp = C.POINTER(C.c_ulonglong)
+        L.bxc_optimize_trace.argtypes = [C.c_char_p, C.POINTER(Params), C.POINTER(Result), C.c_int, C.c_int,
+                                         ip, dp, ullp, ullp, C.POINTER(C.c_uint), C.POINTER(C.c_longlong),
+                                         C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -177,3 +181,31 @@ def preprocess(path, fix_zero=None, affect=None, split=None):
     return dict(info=info, affect=aff, split1=s1, split0=s0,
                 linear=[(int(lv[i]), float(lf[i])) for i in range(info.n_objective)],
                 quadratic=[(int(qa[i]), int(qb[i]), float(qf[i])) for i in range(info.n_quadratic)])
+
+
+def optimize_trace(path, params, nvars):
+    """baryonyx::optimize with the recorder's final state: (Result, dict) with
+    the population best first (x over the `nvars` preprocessed variables), every
+    worker's engine state and restart count, and the rounds run."""
+    L = lib()
+    pop, thread = params.init_population_size, params.thread
+    nwords = nvars // 64 + 1
+    out = dict(
+        pop_remaining=np.zeros(pop, np.int32), pop_value=np.zeros(pop, np.float64),
+        pop_hash=np.zeros(pop, np.uint64), pop_x=np.zeros((pop, nwords), np.uint64),
+        worker_rng=np.zeros(thread, np.uint32), worker_calls=np.zeros(thread, np.int64),
+    )
+    res = Result()
+    rounds = C.c_longlong()
+    err = C.create_string_buffer(256)
+    ip, dp, ullp = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)
+    rc = L.bxc_optimize_trace(
+        os.fsencode(path), C.byref(params), C.byref(res), pop, nwords,
+        out["pop_remaining"].ctypes.data_as(ip), out["pop_value"].ctypes.data_as(dp),
+        out["pop_hash"].ctypes.data_as(ullp), out["pop_x"].ctypes.data_as(ullp),
+        out["worker_rng"].ctypes.data_as(C.POINTER(C.c_uint)),
+        out["worker_calls"].ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(rounds), err, 256)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    out["rounds"] = rounds.value
+    return res, out

@@ -2,6 +2,7 @@
 // extern "C" surface over oracle/itm_oracle.hpp (see oracle_capi.h).
 #include "oracle_capi.h"
 #include "itm_oracle.hpp"
+#include "itm_oracle_opt.hpp"
 
 #include <sstream>
 #include <string>
@@ -532,6 +533,64 @@ orc_solve(const orc_problem* pb,
         out->sweeps = r.sweeps;
         if (out_x_words && r.has_solution_vector)
             std::copy(r.best.x.w.begin(), r.best.x.w.end(), out_x_words);
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+
+int
+orc_optimize(const orc_problem* pb,
+             int kind,
+             int float_type,
+             int maximize,
+             const orc_params* params,
+             int thread,
+             int64_t rounds,
+             orc_result* out,
+             int32_t* pop_remaining,
+             double* pop_value,
+             uint64_t* pop_hash,
+             uint64_t* pop_x,
+             uint32_t* worker_rng,
+             int64_t* worker_calls)
+{
+    try {
+        orc::Constraints cs;
+        orc::Objective obj;
+        fill(cs, obj, pb);
+        const orc::Params p = to_params(params);
+        if (thread < 1 || rounds < 0 || p.seed == 0)
+            throw std::invalid_argument("orc_optimize: thread >= 1, rounds >= 0, seed > 0");
+        const orc::OptimizeResult r =
+          float_type == 0
+            ? orc::optimize<float>(cs, obj, kind, maximize != 0, p, thread, static_cast<long>(rounds))
+            : orc::optimize<double>(cs, obj, kind, maximize != 0, p, thread, static_cast<long>(rounds));
+        out->status = r.status;
+        out->remaining_constraints = r.remaining_constraints;
+        out->has_solution_vector = 1;
+        out->value = r.population.front().value;
+        out->loop = r.loop;
+        out->row_updates = r.row_updates;
+        out->sweeps = static_cast<uint64_t>(r.rounds);
+        const size_t nwords = static_cast<size_t>(cs.n / 64 + 1);
+        for (size_t i = 0; i != r.population.size(); ++i) {
+            if (pop_remaining)
+                pop_remaining[i] = r.population[i].remaining_constraints;
+            if (pop_value)
+                pop_value[i] = r.population[i].value;
+            if (pop_hash)
+                pop_hash[i] = r.population[i].hash;
+            if (pop_x)
+                std::copy(r.population[i].x.w.begin(), r.population[i].x.w.end(), pop_x + i * nwords);
+        }
+        for (int i = 0; i != thread; ++i) {
+            if (worker_rng)
+                worker_rng[i] = r.worker_rng[static_cast<size_t>(i)];
+            if (worker_calls)
+                worker_calls[i] = r.worker_calls[static_cast<size_t>(i)];
+        }
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();

@@ -126,6 +126,25 @@ int orc_solve(const orc_problem* pb,
               orc_result* out,
               uint64_t* out_x_words);
 
+/* optimize_problem (itm-optimizer-common.hpp:776-908) with `thread` workers for
+ * `rounds` rounds of the deterministic schedule of oracle/itm_oracle_opt.hpp.
+ * out: the incumbent; pop_*: the whole population, best first ([population]
+ * entries; pop_x [population][nwords]); worker_*: [thread]. */
+int orc_optimize(const orc_problem* pb,
+                 int kind,
+                 int float_type,
+                 int maximize,
+                 const orc_params* params,
+                 int thread,
+                 int64_t rounds,
+                 orc_result* out,
+                 int32_t* pop_remaining,
+                 double* pop_value,
+                 uint64_t* pop_hash,
+                 uint64_t* pop_x,
+                 uint32_t* worker_rng,
+                 int64_t* worker_calls);
+
 /* Z sub-solvers on their own (lib/test/lib.cpp:376-563) */
 int orc_bb_solve(int maximize,
                  int n,

@@ -83,7 +83,7 @@ class OrcResult(C.Structure):
 def build(force: bool = False) -> str:
     """Compile oracle/liboracle.so with the committed Makefile."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = ["oracle_capi.cpp", "oracle_capi.h", "itm_oracle.hpp", "itm_oracle_z.hpp"]
+    srcs = ["oracle_capi.cpp", "oracle_capi.h", "itm_oracle.hpp", "itm_oracle_z.hpp", "itm_oracle_opt.hpp"]
     stale = force or not os.path.exists(so)
     if not stale:
         t = os.path.getmtime(so)
@@ -143,6 +143,12 @@ def lib():
             C.POINTER(OrcParams), C.POINTER(OrcResult), u64p,
         ]
         L.orc_solve.restype = C.c_int
+        L.orc_optimize.argtypes = [
+            C.POINTER(OrcProblem), C.c_int, C.c_int, C.c_int, C.POINTER(OrcParams), C.c_int,
+            C.c_int64, C.POINTER(OrcResult), i32p, f64p, u64p, u64p,
+            C.POINTER(C.c_uint32), C.POINTER(C.c_int64),
+        ]
+        L.orc_optimize.restype = C.c_int
         L.orc_default_params.argtypes = [C.POINTER(OrcParams)]
         L.orc_bb_solve.argtypes = [C.c_int, C.c_int, f64p, i32p, i32p, C.c_int, C.c_int]
         L.orc_bb_solve.restype = C.c_int
@@ -341,3 +347,31 @@ def solve(inst, float_type=1, params=None, kind=None, maximize=None):
     if rc != 0:
         raise RuntimeError(L.orc_last_error().decode())
     return res, xw
+
+
+def optimize(inst, float_type=1, params=None, thread=4, rounds=100, kind=None, maximize=None):
+    """optimize_problem for `rounds` rounds of the deterministic schedule (see
+    itm_oracle_opt.hpp).  Returns (OrcResult, dict(pop_remaining, pop_value,
+    pop_hash, pop_x, worker_rng, worker_calls))."""
+    L = lib()
+    pb = Problem(inst)
+    p = params or default_params()
+    res = OrcResult()
+    pop = p.init_population_size
+    nwords = inst.n // 64 + 1
+    out = dict(
+        pop_remaining=np.zeros(pop, np.int32), pop_value=np.zeros(pop, np.float64),
+        pop_hash=np.zeros(pop, np.uint64), pop_x=np.zeros((pop, nwords), np.uint64),
+        worker_rng=np.zeros(thread, np.uint32), worker_calls=np.zeros(thread, np.int64),
+    )
+    rc = L.orc_optimize(
+        C.byref(pb.c), inst.kind if kind is None else kind, float_type,
+        int(inst.maximize if maximize is None else maximize), C.byref(p), thread, rounds,
+        C.byref(res), _p(out["pop_remaining"], i32p), _p(out["pop_value"], f64p),
+        _p(out["pop_hash"], u64p), _p(out["pop_x"], u64p),
+        out["worker_rng"].ctypes.data_as(C.POINTER(C.c_uint32)),
+        out["worker_calls"].ctypes.data_as(C.POINTER(C.c_int64)),
+    )
+    if rc != 0:
+        raise RuntimeError(L.orc_last_error().decode())
+    return res, out

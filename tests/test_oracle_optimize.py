@@ -1,0 +1,76 @@
+"""The oracle's optimize() (oracle/itm_oracle_opt.hpp: optimize_functor +
+storage + best_solution_recorder restated, lib/src/itm-optimizer-common.hpp:
+54-908) on the CPU: the deterministic schedule really is deterministic, the
+population keeps storage's invariants, and what lib/test/optimize.cpp:55-90
+expects of small4.lp (optimize reaches 790) is examined with the restated loop."""
+import os
+
+import numpy as np
+import pytest
+
+from baryonyx_amd import synth
+from helpers import is_feasible, objective
+
+LP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lp")
+
+
+def violated(inst, words):
+    from helpers import x_bits
+    x = x_bits(words, inst.n).astype(np.int64)
+    v = np.add.reduceat(inst.factor.astype(np.int64) * x[inst.col], inst.row_ptr[:-1])
+    return int(((v < inst.cmin) | (v > inst.cmax)).sum())
+
+
+@pytest.mark.parametrize("maker,kw", [
+    (lambda: synth.make_scp(60, 400, 0.06, "int", 12), dict(limit=100, w=5.0)),
+    (lambda: synth.make_spp(40, 300, 0.06, "int", 17), dict(limit=60, w=5.0, order=2)),
+    (lambda: synth.make_pm1(50, 250, 0.06, "real", 20), dict(limit=80, w=5.0, pushes_limit=3)),
+    (lambda: synth.make_z(20, 60, 0.2, "int", 11), dict(limit=50, w=5.0, pushes_limit=2,
+                                                        pushing_iteration_limit=5)),
+], ids=["scp", "spp", "pm1", "z"])
+def test_schedule_is_deterministic_and_population_is_consistent(oracle, maker, kw):
+    inst = maker()
+    p = oracle.default_params(seed=77, sort_mode=1, init_population_size=20, **kw)
+    r1, o1 = oracle.optimize(inst, 1, p, thread=5, rounds=250)
+    r2, o2 = oracle.optimize(inst, 1, p, thread=5, rounds=250)
+    assert (r1.status, r1.value, r1.loop, r1.remaining_constraints, r1.row_updates) == \
+           (r2.status, r2.value, r2.loop, r2.remaining_constraints, r2.row_updates)
+    for k in o1:
+        assert np.array_equal(o1[k], o2[k]), k
+    assert r1.sweeps == 250 and int(o1["worker_calls"].min()) >= 1
+    # storage::sort (:424-442): by remaining constraints, then by value
+    rem, val = o1["pop_remaining"], o1["pop_value"]
+    for i in range(len(rem) - 1):
+        assert rem[i] < rem[i + 1] or (rem[i] == rem[i + 1] and not
+                                       (val[i + 1] > val[i] if inst.maximize else val[i + 1] < val[i]))
+    # (an infeasible entry holds the LAST x of its run with the SMALLEST number of
+    # violated rows the run saw, try_advance :696-698; entries crossover overwrote
+    # with the Bastert / a random point keep their old value and hash, :390,402 --
+    # the reference's quirks -- so only a feasible incumbent is held to its x)
+    if rem[0] == 0:
+        assert r1.status == 0 and is_feasible(inst, o1["pop_x"][0])
+        assert val[0] == objective(inst, o1["pop_x"][0])
+    # more rounds never make the incumbent worse
+    r3, _ = oracle.optimize(inst, 1, p, thread=5, rounds=400)
+    assert (r3.remaining_constraints, r3.value if not inst.maximize else -r3.value) <= \
+           (r1.remaining_constraints, r1.value if not inst.maximize else -r1.value)
+
+
+def test_qap_small4_with_the_reference_tests_parameters(oracle):
+    """lib/test/optimize.cpp:55-90 expects optimize() to reach 790 on small4.lp
+    within 40 s on 2 threads (the test is excluded from the reference's CI,
+    .travis.yml:100-111).  With that test's parameters the restated loop -- both
+    tie rules, several seeds, 60 000 rounds (~7 restarts per worker, each running
+    into kappa_max = 10 after 10 000 sweeps) -- never satisfies the eight
+    `sum x = 1` rows of the instance: kappa passes 1, where kappa / (1 - kappa)
+    changes sign.  Recorded here as what the restatement does; the reference
+    cannot be run in this environment to tell whether its own test passes."""
+    from baryonyx_amd import host_ffi as H
+    inst = H.merged(os.path.join(LP, "small4.lp"))
+    assert (inst.m, inst.n, inst.kind) == (136, 272, 2)
+    p = oracle.default_params(seed=1, sort_mode=0, limit=2**62, theta=0.5, delta=0.2, kappa_step=10e-4,
+                              kappa_max=10.0, alpha=0.0, w=20.0, pushing_k_factor=0.9, pushes_limit=50,
+                              pushing_objective_amplifier=10.0, pushing_iteration_limit=50)
+    r, o = oracle.optimize(inst, 1, p, thread=2, rounds=12000)
+    assert r.status == 3 and r.remaining_constraints == 8  # time_limit_reached, 8 rows violated
+    assert o["pop_remaining"][0] == 8
