@@ -580,8 +580,9 @@ bxh_create(const bxh_problem* pb,
                 col_row[at] = k;
                 row_pos[e] = q;
                 if (pm1) {
-                    fac_csr[e] = static_cast<signed char>(pb->factor[e]);
-                    if (pb->factor[e] < 0)
+                    const int fe = pb->factor ? pb->factor[e] : 1; // (NULL = all +1)
+                    fac_csr[e] = static_cast<signed char>(fe);
+                    if (fe < 0)
                         col_row[at] |= 0x40000000;
                 }
                 if (zsolver) {
@@ -1064,7 +1065,7 @@ bxh_create(const bxh_problem* pb,
         while (hs < 4 * static_cast<size_t>(rmax))
             hs <<= 1;
         const size_t n2big = rmax > bxh::WIDE_SMALL ? static_cast<size_t>(bxh::next_pow2(rmax)) : 0;
-        HIP_TRY(h->piw.alloc(B * Gz * (static_cast<size_t>(m) + 1) * h->fsize));
+        HIP_TRY(h->piw.alloc((B * Gz * (static_cast<size_t>(m) + 1) + 2 * static_cast<size_t>(h->wp.ring) + 64) * h->fsize)); // (+ slack: the window's refill reads whole quarters)
         HIP_TRY(h->whash.alloc(B * hs));
         HIP_TRY(hipMemset(h->whash.p, 0, B * hs * sizeof(unsigned long long)));
         HIP_TRY(h->wrec.alloc(B * Gz * 8));
@@ -1169,6 +1170,37 @@ bxh_create(const bxh_problem* pb,
             BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, false, true>));
         }
 #undef BXH_SET_LDS
+    }
+
+    // The forms with several workgroups per instance wait for their partners
+    // inside the launch: every workgroup of the grid must be resident at once.
+    // Ask the runtime how many workgroups of this kernel one CU takes.
+    if (wide_g || h->pipe || groups > 1) {
+        int per_cu = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        const void* fn = nullptr;
+        if (wide_g)
+            fn = float_type == BXH_FLOAT
+                   ? (pm1 ? reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, true>)
+                          : reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, false>))
+                   : (pm1 ? reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, true>)
+                          : reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, false>));
+        else if (h->pipe) // (every NP instantiation has the same footprint: 512 threads, the same LDS request)
+            fn = float_type == BXH_FLOAT
+                   ? reinterpret_cast<const void*>(&bxh::sweep_kernel_v2<float, false, 8, false, true>)
+                   : reinterpret_cast<const void*>(&bxh::sweep_kernel_v2<double, false, 8, false, true>);
+        else
+            fn = float_type == BXH_FLOAT
+                   ? reinterpret_cast<const void*>(&bxh::sweep_kernel_v2<float, false, 8, true>)
+                   : reinterpret_cast<const void*>(&bxh::sweep_kernel_v2<double, false, 8, true>);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->threads, h->lds_bytes));
+        const long long grid = static_cast<long long>(batch) * (wide_g ? wide_g : (h->pipe ? h->pipe : groups));
+        if (static_cast<long long>(per_cu) * cus < grid)
+            return fail(BXH_ERR_UNSUPPORTED,
+                        "the cooperating workgroups of all instances would not be resident "
+                        "together on this device");
     }
 
     bxh::DevProblem& dp = h->dp;
@@ -1496,7 +1528,7 @@ bxh_create_device(const bxh_problem* pb,
     while (hs < 4 * static_cast<size_t>(rmax))
         hs <<= 1;
     const size_t n2big = rmax > bxh::WIDE_SMALL ? static_cast<size_t>(bxh::next_pow2(rmax)) : 0;
-    HIP_TRY(h->piw.alloc(B * Gz * (static_cast<size_t>(m) + 1) * h->fsize));
+    HIP_TRY(h->piw.alloc((B * Gz * (static_cast<size_t>(m) + 1) + 2 * static_cast<size_t>(ring) + 64) * h->fsize)); // (+ slack: the window's refill reads whole quarters)
     HIP_TRY(h->whash.alloc(B * hs));
     HIP_TRY(hipMemsetAsync(h->whash.p, 0, B * hs * sizeof(unsigned long long), s));
     HIP_TRY(h->wrec.alloc(B * Gz * 8));

@@ -27,6 +27,8 @@
 
 #include "bxh_kernels.hpp"
 
+#include <type_traits>
+
 namespace bxh {
 
 constexpr int WIDE_T = 512;      // threads of a workgroup
@@ -90,6 +92,9 @@ wide_lds(int G, int chmax, int fsize, int ring)
     auto al = [](int v) { return (v + 15) & ~15; };
     WideLds p;
     int o = 0;
+    // first: the LDS-DMA refill addresses the ring through M0
+    p.off_ring = o; // pi of the rows [lo, lo + ring) by row % ring, + one zero entry (padding)
+    o = al(o + (ring + 1) * fsize);
     p.off_misc = o;
     o = al(o + 128 * 4);
     p.off_part = o;
@@ -105,8 +110,6 @@ wide_lds(int G, int chmax, int fsize, int ring)
     p.off_union = o;
     p.union_bytes = (WIDE_T / 64) * wide_stage_bytes(fsize);
     o = al(o + p.union_bytes);
-    p.off_ring = o; // pi of the rows [lo, lo + ring) by row % ring, + one zero entry (padding)
-    o = al(o + (ring + 1) * fsize);
     p.total = o;
     return p;
 }
@@ -121,23 +124,18 @@ wide_lds(int G, int chmax, int fsize, int ring)
 // VGPRs, a kernel without MFMA never touches them otherwise, and listing them as
 // clobbers makes the kernel descriptor allocate them -- and are moved on by the
 // very asm statement that waits for them:
-//   a[0:23]   staging loads of one 16-entry piece: P (a[0:15] fp64 / a[0:7] fp32:
-//             device-scope sc1 loads, P is written by the other workgroups of
-//             the instance) and row indices (a[16:23], read-only data),
+//   a[24 K : 24 K + 23]  staging loads of one 16-entry piece (K = piece % 3: three
+//             pieces in flight per wave): P (16 registers fp64 / 8 fp32,
+//             device-scope sc1 loads: P is written by the other workgroups of
+//             the instance) and row indices (8 registers, read-only data),
 //             ds_write_b128 straight from the AGPRs.
-#define BXH_WIDE_STAGE_CLOBBER                                                                     \
-    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", \
-      "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23"
-
 template<typename Float>
 struct WideAsm;
 
 template<>
 struct WideAsm<double>
 {
-    // staging loads of one piece: 4 x 16 B of P (8 columns each), 2 x 16 B of indices
-    __device__ static inline void issue(const char* p0, const char* p1, const char* p2,
-                                        const char* p3, const char* i0, const char* i1)
+    __device__ static inline void issue0(const char* p0, const char* p1, const char* p2, const char* p3, const char* i0, const char* i1)
     {
         asm volatile("global_load_dwordx4 a[0:3], %0, off sc1\n"
                      "global_load_dwordx4 a[4:7], %1, off sc1\n"
@@ -147,10 +145,9 @@ struct WideAsm<double>
                      "global_load_dwordx4 a[20:23], %5, off\n"
                      :
                      : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(i0), "v"(i1)
-                     : "memory", BXH_WIDE_STAGE_CLOBBER);
+                     : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
     }
-    // ... have landed (nothing else of this wave is in flight): into the wave's LDS slots
-    __device__ static inline void land(unsigned lds_p, unsigned lds_i)
+    __device__ static inline void land0_w0(unsigned lds_p, unsigned lds_i)
     {
         asm volatile("s_waitcnt vmcnt(0)\n"
                      "ds_write_b128 %0, a[0:3]\n"
@@ -161,15 +158,184 @@ struct WideAsm<double>
                      "ds_write_b128 %1, a[20:23] offset:1280\n"
                      :
                      : "v"(lds_p), "v"(lds_i)
-                     : "memory", BXH_WIDE_STAGE_CLOBBER);
+                     : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
+    }
+    __device__ static inline void land0_w6(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(6)\n"
+                     "ds_write_b128 %0, a[0:3]\n"
+                     "ds_write_b128 %0, a[4:7] offset:1152\n"
+                     "ds_write_b128 %0, a[8:11] offset:2304\n"
+                     "ds_write_b128 %0, a[12:15] offset:3456\n"
+                     "ds_write_b128 %1, a[16:19]\n"
+                     "ds_write_b128 %1, a[20:23] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
+    }
+    __device__ static inline void land0_w12(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(12)\n"
+                     "ds_write_b128 %0, a[0:3]\n"
+                     "ds_write_b128 %0, a[4:7] offset:1152\n"
+                     "ds_write_b128 %0, a[8:11] offset:2304\n"
+                     "ds_write_b128 %0, a[12:15] offset:3456\n"
+                     "ds_write_b128 %1, a[16:19]\n"
+                     "ds_write_b128 %1, a[20:23] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
+    }
+    __device__ static inline void issue1(const char* p0, const char* p1, const char* p2, const char* p3, const char* i0, const char* i1)
+    {
+        asm volatile("global_load_dwordx4 a[24:27], %0, off sc1\n"
+                     "global_load_dwordx4 a[28:31], %1, off sc1\n"
+                     "global_load_dwordx4 a[32:35], %2, off sc1\n"
+                     "global_load_dwordx4 a[36:39], %3, off sc1\n"
+                     "global_load_dwordx4 a[40:43], %4, off\n"
+                     "global_load_dwordx4 a[44:47], %5, off\n"
+                     :
+                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(i0), "v"(i1)
+                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    }
+    __device__ static inline void land1_w0(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(0)\n"
+                     "ds_write_b128 %0, a[24:27]\n"
+                     "ds_write_b128 %0, a[28:31] offset:1152\n"
+                     "ds_write_b128 %0, a[32:35] offset:2304\n"
+                     "ds_write_b128 %0, a[36:39] offset:3456\n"
+                     "ds_write_b128 %1, a[40:43]\n"
+                     "ds_write_b128 %1, a[44:47] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    }
+    __device__ static inline void land1_w6(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(6)\n"
+                     "ds_write_b128 %0, a[24:27]\n"
+                     "ds_write_b128 %0, a[28:31] offset:1152\n"
+                     "ds_write_b128 %0, a[32:35] offset:2304\n"
+                     "ds_write_b128 %0, a[36:39] offset:3456\n"
+                     "ds_write_b128 %1, a[40:43]\n"
+                     "ds_write_b128 %1, a[44:47] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    }
+    __device__ static inline void land1_w12(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(12)\n"
+                     "ds_write_b128 %0, a[24:27]\n"
+                     "ds_write_b128 %0, a[28:31] offset:1152\n"
+                     "ds_write_b128 %0, a[32:35] offset:2304\n"
+                     "ds_write_b128 %0, a[36:39] offset:3456\n"
+                     "ds_write_b128 %1, a[40:43]\n"
+                     "ds_write_b128 %1, a[44:47] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    }
+    __device__ static inline void issue2(const char* p0, const char* p1, const char* p2, const char* p3, const char* i0, const char* i1)
+    {
+        asm volatile("global_load_dwordx4 a[48:51], %0, off sc1\n"
+                     "global_load_dwordx4 a[52:55], %1, off sc1\n"
+                     "global_load_dwordx4 a[56:59], %2, off sc1\n"
+                     "global_load_dwordx4 a[60:63], %3, off sc1\n"
+                     "global_load_dwordx4 a[64:67], %4, off\n"
+                     "global_load_dwordx4 a[68:71], %5, off\n"
+                     :
+                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(i0), "v"(i1)
+                     : "memory", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+    }
+    __device__ static inline void land2_w0(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(0)\n"
+                     "ds_write_b128 %0, a[48:51]\n"
+                     "ds_write_b128 %0, a[52:55] offset:1152\n"
+                     "ds_write_b128 %0, a[56:59] offset:2304\n"
+                     "ds_write_b128 %0, a[60:63] offset:3456\n"
+                     "ds_write_b128 %1, a[64:67]\n"
+                     "ds_write_b128 %1, a[68:71] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+    }
+    __device__ static inline void land2_w6(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(6)\n"
+                     "ds_write_b128 %0, a[48:51]\n"
+                     "ds_write_b128 %0, a[52:55] offset:1152\n"
+                     "ds_write_b128 %0, a[56:59] offset:2304\n"
+                     "ds_write_b128 %0, a[60:63] offset:3456\n"
+                     "ds_write_b128 %1, a[64:67]\n"
+                     "ds_write_b128 %1, a[68:71] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+    }
+    __device__ static inline void land2_w12(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(12)\n"
+                     "ds_write_b128 %0, a[48:51]\n"
+                     "ds_write_b128 %0, a[52:55] offset:1152\n"
+                     "ds_write_b128 %0, a[56:59] offset:2304\n"
+                     "ds_write_b128 %0, a[60:63] offset:3456\n"
+                     "ds_write_b128 %1, a[64:67]\n"
+                     "ds_write_b128 %1, a[68:71] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+    }
+    // staging loads of a piece into register set K (= piece % 3)
+    template<int K>
+    __device__ static inline void issue(const char* p0, const char* p1, const char* p2, const char* p3,
+                                        const char* i0, const char* i1)
+    {
+        if constexpr (K == 0)
+            issue0(p0, p1, p2, p3, i0, i1);
+        else if constexpr (K == 1)
+            issue1(p0, p1, p2, p3, i0, i1);
+        else
+            issue2(p0, p1, p2, p3, i0, i1);
+    }
+    // the loads of set K have landed (`ahead` younger pieces may stay in flight:
+    // vmcnt counts in issue order): into the wave's LDS slots
+    template<int K>
+    __device__ static inline void land(int ahead, unsigned lds_p, unsigned lds_i)
+    {
+        if constexpr (K == 0) {
+            if (ahead >= 2)
+                land0_w12(lds_p, lds_i);
+            else if (ahead == 1)
+                land0_w6(lds_p, lds_i);
+            else
+                land0_w0(lds_p, lds_i);
+        }
+        else if constexpr (K == 1) {
+            if (ahead >= 2)
+                land1_w12(lds_p, lds_i);
+            else if (ahead == 1)
+                land1_w6(lds_p, lds_i);
+            else
+                land1_w0(lds_p, lds_i);
+        }
+        else if constexpr (K == 2) {
+            if (ahead >= 2)
+                land2_w12(lds_p, lds_i);
+            else if (ahead == 1)
+                land2_w6(lds_p, lds_i);
+            else
+                land2_w0(lds_p, lds_i);
+        }
     }
 };
 
 template<>
 struct WideAsm<float>
 {
-    __device__ static inline void issue(const char* p0, const char* p1, const char*, const char*,
-                                        const char* i0, const char* i1)
+    __device__ static inline void issue0(const char* p0, const char* p1, const char*, const char*, const char* i0, const char* i1)
     {
         asm volatile("global_load_dwordx4 a[0:3], %0, off sc1\n"
                      "global_load_dwordx4 a[4:7], %1, off sc1\n"
@@ -177,9 +343,9 @@ struct WideAsm<float>
                      "global_load_dwordx4 a[20:23], %3, off\n"
                      :
                      : "v"(p0), "v"(p1), "v"(i0), "v"(i1)
-                     : "memory", BXH_WIDE_STAGE_CLOBBER);
+                     : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
     }
-    __device__ static inline void land(unsigned lds_p, unsigned lds_i)
+    __device__ static inline void land0_w0(unsigned lds_p, unsigned lds_i)
     {
         asm volatile("s_waitcnt vmcnt(0)\n"
                      "ds_write_b128 %0, a[0:3]\n"
@@ -188,7 +354,159 @@ struct WideAsm<float>
                      "ds_write_b128 %1, a[20:23] offset:1280\n"
                      :
                      : "v"(lds_p), "v"(lds_i)
-                     : "memory", BXH_WIDE_STAGE_CLOBBER);
+                     : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
+    }
+    __device__ static inline void land0_w4(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(4)\n"
+                     "ds_write_b128 %0, a[0:3]\n"
+                     "ds_write_b128 %0, a[4:7] offset:1280\n"
+                     "ds_write_b128 %1, a[16:19]\n"
+                     "ds_write_b128 %1, a[20:23] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
+    }
+    __device__ static inline void land0_w8(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(8)\n"
+                     "ds_write_b128 %0, a[0:3]\n"
+                     "ds_write_b128 %0, a[4:7] offset:1280\n"
+                     "ds_write_b128 %1, a[16:19]\n"
+                     "ds_write_b128 %1, a[20:23] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
+    }
+    __device__ static inline void issue1(const char* p0, const char* p1, const char*, const char*, const char* i0, const char* i1)
+    {
+        asm volatile("global_load_dwordx4 a[24:27], %0, off sc1\n"
+                     "global_load_dwordx4 a[28:31], %1, off sc1\n"
+                     "global_load_dwordx4 a[40:43], %2, off\n"
+                     "global_load_dwordx4 a[44:47], %3, off\n"
+                     :
+                     : "v"(p0), "v"(p1), "v"(i0), "v"(i1)
+                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    }
+    __device__ static inline void land1_w0(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(0)\n"
+                     "ds_write_b128 %0, a[24:27]\n"
+                     "ds_write_b128 %0, a[28:31] offset:1280\n"
+                     "ds_write_b128 %1, a[40:43]\n"
+                     "ds_write_b128 %1, a[44:47] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    }
+    __device__ static inline void land1_w4(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(4)\n"
+                     "ds_write_b128 %0, a[24:27]\n"
+                     "ds_write_b128 %0, a[28:31] offset:1280\n"
+                     "ds_write_b128 %1, a[40:43]\n"
+                     "ds_write_b128 %1, a[44:47] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    }
+    __device__ static inline void land1_w8(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(8)\n"
+                     "ds_write_b128 %0, a[24:27]\n"
+                     "ds_write_b128 %0, a[28:31] offset:1280\n"
+                     "ds_write_b128 %1, a[40:43]\n"
+                     "ds_write_b128 %1, a[44:47] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    }
+    __device__ static inline void issue2(const char* p0, const char* p1, const char*, const char*, const char* i0, const char* i1)
+    {
+        asm volatile("global_load_dwordx4 a[48:51], %0, off sc1\n"
+                     "global_load_dwordx4 a[52:55], %1, off sc1\n"
+                     "global_load_dwordx4 a[64:67], %2, off\n"
+                     "global_load_dwordx4 a[68:71], %3, off\n"
+                     :
+                     : "v"(p0), "v"(p1), "v"(i0), "v"(i1)
+                     : "memory", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+    }
+    __device__ static inline void land2_w0(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(0)\n"
+                     "ds_write_b128 %0, a[48:51]\n"
+                     "ds_write_b128 %0, a[52:55] offset:1280\n"
+                     "ds_write_b128 %1, a[64:67]\n"
+                     "ds_write_b128 %1, a[68:71] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+    }
+    __device__ static inline void land2_w4(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(4)\n"
+                     "ds_write_b128 %0, a[48:51]\n"
+                     "ds_write_b128 %0, a[52:55] offset:1280\n"
+                     "ds_write_b128 %1, a[64:67]\n"
+                     "ds_write_b128 %1, a[68:71] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+    }
+    __device__ static inline void land2_w8(unsigned lds_p, unsigned lds_i)
+    {
+        asm volatile("s_waitcnt vmcnt(8)\n"
+                     "ds_write_b128 %0, a[48:51]\n"
+                     "ds_write_b128 %0, a[52:55] offset:1280\n"
+                     "ds_write_b128 %1, a[64:67]\n"
+                     "ds_write_b128 %1, a[68:71] offset:1280\n"
+                     :
+                     : "v"(lds_p), "v"(lds_i)
+                     : "memory", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+    }
+    // staging loads of a piece into register set K (= piece % 3)
+    template<int K>
+    __device__ static inline void issue(const char* p0, const char* p1, const char* p2, const char* p3,
+                                        const char* i0, const char* i1)
+    {
+        if constexpr (K == 0)
+            issue0(p0, p1, nullptr, nullptr, i0, i1);
+        else if constexpr (K == 1)
+            issue1(p0, p1, nullptr, nullptr, i0, i1);
+        else
+            issue2(p0, p1, nullptr, nullptr, i0, i1);
+        (void)p2;
+        (void)p3;
+    }
+    // the loads of set K have landed (`ahead` younger pieces may stay in flight:
+    // vmcnt counts in issue order): into the wave's LDS slots
+    template<int K>
+    __device__ static inline void land(int ahead, unsigned lds_p, unsigned lds_i)
+    {
+        if constexpr (K == 0) {
+            if (ahead >= 2)
+                land0_w8(lds_p, lds_i);
+            else if (ahead == 1)
+                land0_w4(lds_p, lds_i);
+            else
+                land0_w0(lds_p, lds_i);
+        }
+        else if constexpr (K == 1) {
+            if (ahead >= 2)
+                land1_w8(lds_p, lds_i);
+            else if (ahead == 1)
+                land1_w4(lds_p, lds_i);
+            else
+                land1_w0(lds_p, lds_i);
+        }
+        else if constexpr (K == 2) {
+            if (ahead >= 2)
+                land2_w8(lds_p, lds_i);
+            else if (ahead == 1)
+                land2_w4(lds_p, lds_i);
+            else
+                land2_w0(lds_p, lds_i);
+        }
     }
 };
 
@@ -408,9 +726,51 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
         }
         __syncthreads();
         const int tnp_row = misc_s[WM_TNP];
-        const int RB = wp.ring >> 1;                 // the window moves by half its length
-        const int nblk = (m + RB - 1) / RB;          // blocks of RB rows
+        // The window: the ring holds four quarters of Q rows; three are valid
+        // (q0 .. q0 + 2, centred on the rows of the piece at hand), the fourth is
+        // being refilled by LDS-DMA while the waves stream on.
+        const int Q = wp.ring >> 2;
+        const int nq = (m + Q - 1) / Q;
         const unsigned rmask = (unsigned)wp.ring - 1u;
+        constexpr int NL = Geo::PL + 2; // staging loads of one piece
+        // Round t of tnp_row: every column is at the fraction t / tnp_row of its
+        // entries (a column of np pieces works on piece t * np / tnp_row and rests
+        // in the rounds where that does not move), i.e. -- the rows inside a
+        // column being a sorted sample of 0 .. m - 1 -- near row (t + 1/2) m / tnp_row.
+        const float rows_per_round = (float)m / (float)max(tnp_row, 1);
+        auto quarter_of = [&](int round) -> int {
+            const float centre = ((float)round + 0.5f) * rows_per_round;
+            const int q = (int)(centre / (float)Q - 1.5f);
+            return max(0, min(q, nq - 3));
+        };
+        // (piece of a column of np pieces at round t: t * np / tnp_row, tracked
+        // without a division: acc += np, a carry past tnp_row moves the piece on)
+        auto fill_sync = [&](int qa, int qb) { // quarters [qa, qb) by every thread (nothing in flight)
+            for (int q = qa; q < qb; ++q)
+                for (int i = tid; i < Q; i += T) {
+                    const int rr = q * Q + i;
+                    ring_s[(unsigned)rr & rmask] = rr < m ? piw[rr] : (Float)0;
+                }
+        };
+        auto fill_dma = [&](int q) { // quarter q, asynchronously: 1 KB per wave and instruction
+            const int chunks = Q * (int)sizeof(Float) / 1024;
+            for (int ch = wave; ch < chunks; ch += T / 64) {
+                const size_t row0 = (size_t)q * Q + (size_t)ch * (1024 / sizeof(Float));
+                const char* src = (const char*)(piw + row0) + lane * 16;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                  lds_base + (unsigned)lp.off_ring +
+                  (unsigned)(((unsigned)row0 & rmask) * (unsigned)sizeof(Float)));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n"
+                             "s_mov_b32 m0, %2\n"
+                             "s_nop 0\n"
+                             "global_load_lds_dwordx4 %1, off\n"
+                             "s_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src), "s"(dst)
+                             : "memory");
+            }
+        };
         for (int set = 0; set < nset; ++set) {
             const int tile = set * (T / 64) + wave;
             const int c = lane & 31;
@@ -455,60 +815,101 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 ibase[i] = (const char*)pb.col_row + (size_t)ccs * 4 + (lane & 3) * 16;
             }
             Float sum = 0; // lanes 0-31: sum_a_p of column c, lanes 32-63: sum_a_pi
-            // Software pipeline, one piece ahead: the staging loads of piece t + 1
-            // are issued as soon as piece t has left the accumulator registers
-            // and stay in flight while piece t is summed.
-            auto issue = [&](int piece) {
-                const char* a0 = pbase[0] + (size_t)min(piece, pnp[0] - 1) * (16 * sizeof(Float));
-                const char* a1 = pbase[1] + (size_t)min(piece, pnp[1] - 1) * (16 * sizeof(Float));
-                const char* a2 = pbase[Geo::PL - 2] +
-                                 (size_t)min(piece, pnp[Geo::PL - 2] - 1) * (16 * sizeof(Float));
-                const char* a3 = pbase[Geo::PL - 1] +
-                                 (size_t)min(piece, pnp[Geo::PL - 1] - 1) * (16 * sizeof(Float));
-                const char* b0 = ibase[0] + (size_t)min(piece, inp[0] - 1) * 64;
-                const char* b1 = ibase[1] + (size_t)min(piece, inp[1] - 1) * 64;
-                WideAsm<Float>::issue(a0, a1, a2, a3, b0, b1);
-            };
             const unsigned lds_p = lds_base + (unsigned)(stg_p - smem) +
                                    (unsigned)((lane / Geo::PPARTS) * Geo::PSLOT + (lane % Geo::PPARTS) * 16);
             const unsigned lds_i = lds_base + (unsigned)(stg_i - smem) +
                                    (unsigned)((lane >> 2) * WIDE_ISLOT + (lane & 3) * 16);
-            if (tnp > 0)
-                issue(0);
-            int cur_b0 = -2; // first block of the window in LDS
-            for (int piece = 0; piece < tnp_row; ++piece) {
-                // ---- the window: blocks b0 and b0 + 1, centred on this piece's rows
-                {
-                    const float centre = ((float)piece + 0.5f) * wp.rows_per_piece;
-                    int b0 = (int)(centre / (float)RB - 0.5f);
-                    b0 = max(0, min(b0, nblk - 2));
-                    if (b0 != cur_b0) {
-                        __syncthreads(); // every wave is done with the blocks that go
-                        for (int bb = (b0 == cur_b0 + 1 ? b0 + 1 : b0); bb <= b0 + 1; ++bb)
-                            for (int i = tid; i < RB; i += T) {
-                                const int rr = bb * RB + i;
-                                ring_s[(unsigned)rr & rmask] = rr < m ? piw[rr] : (Float)0;
-                            }
-                        cur_b0 = b0;
-                        __syncthreads();
+
+            // the window at piece 0: the whole ring, by every thread (the set before
+            // has drained: nothing of any wave is in flight)
+            int q0 = quarter_of(0);
+            fill_sync(q0, q0 + 4);
+            __syncthreads();
+            int since_adv = 3; // pieces since the last refill was issued (3: none pending)
+
+            // Software pipeline, three pieces ahead: piece p lives in register set
+            // p % 3 from its issue (behind the landing of piece p - 3) to its landing.
+            // staging loads of round `rnd` into register set K: every column's
+            // piece of that round (a column that rests is loaded again: its 8 or 4
+            // lanes could be masked, but a wave-instruction costs the same)
+            int pacc[Geo::PL], iacc[2]; // (rounds are issued in order, each once)
+#pragma unroll
+            for (int i = 0; i < Geo::PL; ++i)
+                pacc[i] = 0;
+            iacc[0] = iacc[1] = 0;
+            auto issue_round = [&](auto kc, int) {
+                constexpr int K = decltype(kc)::value;
+                WideAsm<Float>::template issue<K>(pbase[0], pbase[1], pbase[Geo::PL - 2],
+                                                  pbase[Geo::PL - 1], ibase[0], ibase[1]);
+#pragma unroll
+                for (int i = 0; i < Geo::PL; ++i) {
+                    pacc[i] += pnp[i];
+                    if (pacc[i] >= tnp_row) {
+                        pacc[i] -= tnp_row;
+                        pbase[i] += 16 * sizeof(Float);
                     }
                 }
-                if (piece >= tnp)
-                    continue; // (this wave's tile is shorter: it only keeps the barriers)
-                const int lo = cur_b0 * RB;
-                WideAsm<Float>::land(lds_p, lds_i);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    iacc[i] += inp[i];
+                    if (iacc[i] >= tnp_row) {
+                        iacc[i] -= tnp_row;
+                        ibase[i] += 64;
+                    }
+                }
+            };
+            int oacc = 0; // this lane's own column
+            const bool streaming = tnp > 0; // this wave has a tile in this set
+            auto body = [&](auto kc, int piece) { // `piece`: the round
+                constexpr int K = decltype(kc)::value;
+                // staging sets of this wave in flight (one per round, to the last round)
+                const int inflight = streaming ? min(3, tnp_row - piece) : 0;
+                // ---- the window moves on?  (uniform over the workgroup)
+                const int qn = quarter_of(piece);
+                if (qn != q0) {
+                    // the refill issued at the last move has landed (it is older than
+                    // all but min(since_adv, inflight) of the sets in flight) ...
+                    const int younger = min(min(since_adv, 2), inflight);
+                    if (younger >= 2)
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+                    else if (younger == 1)
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads(); // ... in every wave, and nobody reads quarter q0 any more
+                    if (qn == q0 + 1) {
+                        fill_dma(q0 + 4); // into q0's slots; valid from the NEXT move on
+                        since_adv = 0;
+                    } else { // (columns far apart from the matrix average: start over)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        fill_sync(qn, qn + 4);
+                        __syncthreads();
+                        since_adv = 3;
+                    }
+                    q0 = qn;
+                }
+                ++since_adv;
+                if (!streaming)
+                    return; // (no tile of this set: the wave only keeps the barriers)
+                const int lo = q0 * Q;
+                WideAsm<Float>::template land<K>(inflight - 1, lds_p, lds_i);
                 // (the slots are this wave's own: no barrier, but the compiler must
                 // keep the other lanes' writes in front of this lane's reads)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const bool act = piece < np;
+                // this column moves on in this round?
+                oacc += np;
+                const bool act = oacc >= tnp_row;
+                if (act)
+                    oacc -= tnp_row;
                 const int* ip = (const int*)(stg_i + c * WIDE_ISLOT);
                 int ri[16];
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
                     ri[t] = ip[t];
-                if (piece + 1 < tnp)
-                    issue(piece + 1);
+                if (piece + 3 < tnp_row)
+                    issue_round(kc, piece + 3);
                 if (prole) {
                     if (act) {
                         const Float* sp = (const Float*)(stg_p + c * Geo::PSLOT);
@@ -524,12 +925,12 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                     }
                 } else {
                     Float piv[16];
-                    unsigned out = 0; // entries whose row is outside the window
+                    unsigned out = 0; // entries whose row is outside the three valid quarters
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
                         const int rr = ri[t] & 0x3fffffff;
                         const bool pad = rr == m;
-                        const bool in = pad || (unsigned)(rr - lo) < (unsigned)wp.ring;
+                        const bool in = pad || (unsigned)(rr - lo) < (unsigned)(3 * Q);
                         piv[t] = ring_s[pad ? (unsigned)wp.ring : ((unsigned)rr & rmask)];
                         out |= (in || !act) ? 0u : (1u << t);
                     }
@@ -552,7 +953,24 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier(); // reads done before the next piece is staged
+            };
+            if (streaming) {
+                issue_round(std::integral_constant<int, 0>{}, 0);
+                if (tnp_row > 1)
+                    issue_round(std::integral_constant<int, 1>{}, 1);
+                if (tnp_row > 2)
+                    issue_round(std::integral_constant<int, 2>{}, 2);
             }
+            for (int p0 = 0; p0 < tnp_row; p0 += 3) {
+                body(std::integral_constant<int, 0>{}, p0);
+                if (p0 + 1 < tnp_row)
+                    body(std::integral_constant<int, 1>{}, p0 + 1);
+                if (p0 + 2 < tnp_row)
+                    body(std::integral_constant<int, 2>{}, p0 + 2);
+            }
+            // a refill may still be on its way: the next set refills the ring itself
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             const Float sum_a_pi = __shfl(sum, c + 32, 64);
             if (prole && valid) {
                 Float v = cj - sum_a_pi - sum;

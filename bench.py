@@ -279,6 +279,7 @@ class XLWorkload:
         # instances: what fits beside the matrix (CSR columns + column view +
         # element -> slot map = 12 B per element, the build's counters 1 KB per
         # column for a moment) with 3 % of HBM left alone
+        torch.cuda.empty_cache()
         free, total = torch.cuda.mem_get_info(device)
         nnzp = nnz + 16 * n
         shared = 8 * nnz + 4 * nnzp + 1100 * n
@@ -327,6 +328,9 @@ class XLWorkload:
 
     def step(self, k):
         x = self.restart_points(k)
+        # (torch's default stream is the legacy null stream, which bxh_set_stream
+        # takes as "use the handle's own": x must be complete before the copy)
+        self.torch.cuda.current_stream().synchronize()
         self.dev.set_x_all_device(x.data_ptr(), keep=(x, self._x))
         self._x = x
         self.dev.order_init(self.params.order, sync=False)

@@ -36,7 +36,10 @@ enum bxh_error
     BXH_ERR_OOM = -2,         /* -> solver_failure(not_enough_memory),
                                  lib/include/baryonyx/core:258-263            */
     BXH_ERR_UNSUPPORTED = -3, /* valid in the reference, not on the device yet */
-    BXH_ERR_DEVICE = -4       /* HIP runtime error (see bxh_last_error)       */
+    BXH_ERR_DEVICE = -4       /* HIP runtime error (see bxh_last_error), or a
+                                 workgroup gave up waiting for its partners: the
+                                 state of the handle's instances is undefined
+                                 from then on, destroy the handle              */
 };
 
 /* Solver family == which itm-solver-*.cpp the handle replaces. */
