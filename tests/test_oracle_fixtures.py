@@ -95,3 +95,26 @@ def test_synthetic_families_solve(oracle, maker):
         assert is_feasible(inst, xw) and res.value == objective(inst, xw)
     else:  # the heuristic may stop on its limits; it must say so
         assert res.status in (4, 5) and res.remaining_constraints > 0
+
+
+@pytest.mark.parametrize("sort_mode", [0, 1], ids=["std_sort", "canonical"])
+@pytest.mark.parametrize("seed", [1, 2, 123456789])
+def test_capmo1_direct_default_solve(oracle, seed, sort_mode):
+    """lib/test/solve.cpp:197-240 (`test_preprocessor_2`): solve() with the
+    default parameters on capmo1_direct.lp (10 100 merged constraints,
+    inequalities-01; the reference seeds from the clock) must give a valid
+    solution whose recomputed value equals the reported one.  Pinned here on the
+    restatement for three seeds.
+
+    The reference's third expectation, `value < 1156908`, is NOT reproduced: the
+    values found (7.3 - 7.9e6 for these seeds) are of the size the test's own
+    print statement names ("result.value ... == 6212977"), both far above that
+    bound.  The reference cannot be run here to see whether its `expect` passes
+    (a failing boost.ut `expect` does not abort the test); recorded as an open
+    difference in DESIGN.md section 4."""
+    inst = H.merged(os.path.join(LP, "capmo1_direct.lp"))
+    assert (inst.m, inst.n, inst.kind) == (10100, 10100, 1)
+    res, xw = oracle.solve(inst, 1, oracle.default_params(seed=seed, sort_mode=sort_mode))
+    assert res.status == 0
+    assert is_feasible(inst, xw)
+    assert res.value == objective(inst, xw)
