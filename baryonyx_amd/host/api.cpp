@@ -30,7 +30,17 @@ context_set_parameters(const context_ptr& ctx, const std::string& name, std::str
         ctx->method = std::move(value);
     else if (name == "device") // extension: HIP device ordinal of the batch
         ctx->device = std::stoi(value);
-    else if (name == "sweep-budget") // extension: bounded optimize() for tests
+    else if (name == "devices") { // extension: optimize() over several HIP devices
+        ctx->devices.clear();
+        std::size_t at = 0;
+        while (at < value.size()) {
+            std::size_t used = 0;
+            ctx->devices.push_back(std::stoi(value.substr(at), &used));
+            at += used;
+            while (at < value.size() && (value[at] == ',' || value[at] == ' '))
+                ++at;
+        }
+    } else if (name == "sweep-budget") // extension: bounded optimize() for tests
         ctx->sweep_budget = std::stol(value);
 }
 

@@ -3,6 +3,7 @@
 // solve and optimize without a C++ test runner.
 #include "private.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -99,6 +100,8 @@ make_ctx(const bxc_params* p)
     q.preprocessor = static_cast<solver_parameters::preprocessor_options>(p->preprocessor);
     context_set_solver_parameters(ctx, q);
     context_set_parameters(ctx, "device", std::to_string(p->device));
+    if (const char* dl = std::getenv("BXC_DEVICES")) // e.g. "0,1,2,3": optimize() over several devices
+        context_set_parameters(ctx, "devices", dl);
     if (p->sweep_budget > 0)
         context_set_parameters(ctx, "sweep-budget", std::to_string(p->sweep_budget));
     return ctx;

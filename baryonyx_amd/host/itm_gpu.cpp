@@ -357,7 +357,8 @@ struct device_batch
                  const cost_type<Float>& norm_costs,
                  int kind,
                  bool maximize,
-                 int batch_)
+                 int batch_,
+                 int device = -1)
       : batch(batch_)
       , m(static_cast<int>(csts.size()))
       , n(variables)
@@ -393,7 +394,8 @@ struct device_batch
             pb.q_factor = qf.data();
         }
         const int ft = sizeof(Float) == 4 ? BXH_FLOAT : BXH_DOUBLE;
-        const int rc = bxh_create(&pb, kind, ft, maximize ? 1 : 0, batch, ctx.device, &h);
+        const int rc = bxh_create(&pb, kind, ft, maximize ? 1 : 0, batch,
+                                  device < 0 ? ctx.device : device, &h);
         if (rc == BXH_ERR_OOM)
             throw solver_failure(solver_error_tag::not_enough_memory);
         if (rc != BXH_OK)
@@ -451,6 +453,100 @@ struct device_batch
         check(bxh_sweep_async(h, &a));
     }
     void sync() { check(bxh_status_sync(h, status.data())); }
+};
+
+// The worker pool of optimize() over several devices: worker b lives on device
+// b % D as instance b / D of that device's batch (one process drives all of
+// them; the population stays on the host, shared by every worker as the
+// reference shares its storage between threads, so there is no collective on
+// the path: the incumbent is whatever the shared recorder holds).
+struct device_pool
+{
+    std::vector<std::unique_ptr<device_batch>> dev;
+    int workers = 0, m = 0;
+    struct ref
+    {
+        device_batch* d;
+        int i;
+    };
+    std::vector<ref> at;
+    struct proxy_kappa
+    {
+        device_pool& p;
+        double& operator[](int b) { return p.at[b].d->kappa[p.at[b].i]; }
+    } kappa{ *this };
+    struct proxy_active
+    {
+        device_pool& p;
+        std::uint8_t& operator[](int b) { return p.at[b].d->active[p.at[b].i]; }
+    } active{ *this };
+    struct proxy_status
+    {
+        device_pool& p;
+        bxh_status& operator[](int b) { return p.at[b].d->status[p.at[b].i]; }
+    } status{ *this };
+
+    template<typename Float>
+    device_pool(const context& ctx,
+                const std::vector<merged_constraint>& csts,
+                int variables,
+                const cost_type<Float>& norm_costs,
+                int kind,
+                bool maximize,
+                int workers_)
+      : workers(workers_)
+    {
+        std::vector<int> ids = ctx.devices.empty() ? std::vector<int>{ ctx.device } : ctx.devices;
+        if (static_cast<int>(ids.size()) > workers)
+            ids.resize(static_cast<size_t>(workers));
+        const int D = static_cast<int>(ids.size());
+        for (int d = 0; d != D; ++d) {
+            const int share = (workers - d + D - 1) / D; // workers d, d + D, ...
+            dev.emplace_back(std::make_unique<device_batch>(ctx, csts, variables, norm_costs, kind,
+                                                            maximize, share, ids[d]));
+        }
+        for (int b = 0; b != workers; ++b)
+            at.push_back(ref{ dev[static_cast<size_t>(b % D)].get(), b / D });
+        m = dev[0]->m;
+    }
+    void set_x(int b, const bit_array& x) { at[b].d->set_x(at[b].i, x); }
+    void get_x(int b, bit_array& x) { at[b].d->get_x(at[b].i, x); }
+    void set_rng(int b, const random_engine& e) { at[b].d->set_rng(at[b].i, e); }
+    void order_create(int order)
+    {
+        for (auto& d : dev)
+            d->order_create(order);
+    }
+    void order_init(int order, const std::vector<std::uint8_t>* mask)
+    {
+        const int D = static_cast<int>(dev.size());
+        for (int d = 0; d != D; ++d) {
+            std::vector<std::uint8_t> local(static_cast<size_t>(dev[d]->batch), 0);
+            bool any = false;
+            for (int i = 0; i != dev[d]->batch; ++i) {
+                local[i] = mask ? (*mask)[static_cast<size_t>(i * D + d)] : 1;
+                any = any || local[i];
+            }
+            if (any)
+                dev[d]->order_init(order, &local);
+        }
+    }
+    // one sweep of the active workers on every device (launched on all, then awaited)
+    void sweep_async(double delta, double theta, bool push, double obj_amp, int order)
+    {
+        for (auto& d : dev) {
+            bool any = false;
+            for (auto a : d->active)
+                any = any || a;
+            if (any)
+                d->sweep_async(delta, theta, push, obj_amp, order);
+        }
+    }
+    void sync()
+    {
+        for (auto& d : dev)
+            d->sync();
+    }
 };
 
 int
@@ -978,8 +1074,8 @@ optimize_problem(const context& ctx, const problem& pb)
     const long w_limit = static_cast<long>(p.w);
     const int order = static_cast<int>(p.order);
 
-    device_batch slv(ctx, constraints, variables, norm_costs, device_kind(pb.problem_type),
-                     maximize, workers);
+    device_pool slv(ctx, constraints, variables, norm_costs, device_kind(pb.problem_type),
+                    maximize, workers);
 
     struct worker
     {

@@ -35,6 +35,9 @@ struct context
     solver_finished_cb finish;
     int log_priority = 6;
     int device = 0; // HIP device of the batch (context_set_parameters("device"))
+    // optimize(): the HIP devices the workers are dealt to, round robin
+    // (context_set_parameters("devices", "0,1,2,3"); empty: `device` alone)
+    std::vector<int> devices;
     long sweep_budget = 0; // > 0: optimize() also stops after that many
                            // lock-step sweeps (context_set_parameters("sweep-budget"))
     struct optimize_trace* trace = nullptr; // tests: the recorder's final state

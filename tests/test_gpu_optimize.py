@@ -103,3 +103,25 @@ def test_solve_init_policies_and_cost_norms_match_oracle(oracle, tmp_path, maker
     if res.status == 0:
         assert res.valid == 1 and ores.value == res.value == res.recomputed_value
         assert np.array_equal(pack_bits(x[: inst.n].astype(np.uint8)), oxw)
+
+
+def test_optimize_over_several_devices_is_the_same_run(oracle, tmp_path, monkeypatch):
+    """baryonyx::optimize deals its workers to the devices of
+    context_set_parameters("devices", ...) round robin (one host recorder shared
+    by all of them: no collective on the path): the schedule does
+    not depend on where a worker lives, so three "devices" (here all device 0: one
+    batch of instances each) give the run of one device, which is the oracle's."""
+    path = str(tmp_path / "p.lp")
+    synth.write_lp(synth.make_scp(60, 400, 0.06, "int", 12), path)
+    inst = H.merged(path)
+    hp, okw = both_params(oracle, seed=99, thread=8, float_type=1, sweep_budget=250, time_limit=600.0,
+                          limit=100, w=5.0, init_population_size=20)
+    monkeypatch.delenv("BXC_DEVICES", raising=False)
+    res1, tr1 = H.optimize_trace(path, hp, inst.n)
+    monkeypatch.setenv("BXC_DEVICES", "0,0,0")
+    res3, tr3 = H.optimize_trace(path, hp, inst.n)
+    for k in tr1:
+        assert np.array_equal(tr1[k], tr3[k]), k
+    assert (res1.value, res1.loop, res1.remaining_constraints) == (res3.value, res3.loop, res3.remaining_constraints)
+    ores, otr = oracle.optimize(inst, 1, oracle.default_params(sort_mode=1, **okw), thread=8, rounds=250)
+    assert np.array_equal(tr3["pop_hash"], otr["pop_hash"]) and np.array_equal(tr3["worker_rng"], otr["worker_rng"])
