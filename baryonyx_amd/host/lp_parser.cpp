@@ -254,9 +254,30 @@ to_bound(double v)
     return static_cast<int>(v);
 }
 
+// Where a variable already sits in the function being read: (stamp of that
+// function, position) per variable.
+struct seen_table
+{
+    std::vector<std::pair<int, int>> at;
+    int find(int id, int stamp) const
+    {
+        return static_cast<size_t>(id) < at.size() && at[static_cast<size_t>(id)].first == stamp
+                 ? at[static_cast<size_t>(id)].second
+                 : -1;
+    }
+    void mark(int id, int stamp, int pos)
+    {
+        if (static_cast<size_t>(id) >= at.size())
+            at.resize(static_cast<size_t>(id) + 1 + at.size() / 2, std::make_pair(-1, -1));
+        at[static_cast<size_t>(id)] = std::make_pair(stamp, pos);
+    }
+};
+
 file_format_error_tag
 parse(lexer& lx, builder& b)
 {
+    seen_table seen;
+    int stamp_counter = 0; // 0: the objective, then one per constraint
     using tag = file_format_error_tag;
 
     if (ieq(lx.peek(), "maximize") || ieq(lx.peek(), "maximum") || ieq(lx.peek(), "max"))
@@ -325,15 +346,18 @@ parse(lexer& lx, builder& b)
         if (t->name.empty()) {
             b.pb.objective.value += t->factor;
         } else {
+            // (a variable named twice adds up, lib/src/parser.cpp:1133-1141 -- found
+            // there by a scan of the elements read so far, O(r^2) per function; here by
+            // a stamp per variable: the set-covering files of 1e6 columns parse in
+            // linear time)
             const int id = b.variable(t->name);
             auto& el = b.pb.objective.elements;
-            auto it = std::find_if(el.begin(), el.end(), [id](const auto& e) {
-                return e.variable_index == id;
-            });
-            if (it == el.end())
+            const int pos = seen.find(id, 0);
+            if (pos < 0) {
+                seen.mark(id, 0, static_cast<int>(el.size()));
                 el.emplace_back(t->factor, id);
-            else
-                it->factor += t->factor;
+            } else
+                el[static_cast<size_t>(pos)].factor += t->factor;
         }
     }
 
@@ -352,18 +376,19 @@ parse(lexer& lx, builder& b)
                     lx.pop(2);
                 }
                 std::vector<function_element> elements;
+                const int stamp = ++stamp_counter;
                 bool first = true;
                 while (!lx.end() && lx.peek() != "<" && lx.peek() != ">" && lx.peek() != "=") {
                     auto t = read_term(lx);
                     if (!t || t->name.empty())
                         return tag::bad_constraint;
                     const int id = b.variable(t->name);
-                    auto it = std::find_if(elements.begin(), elements.end(),
-                                           [id](const auto& e) { return e.variable_index == id; });
-                    if (it == elements.end())
+                    const int pos = seen.find(id, stamp); // (:1159-1170, in linear time)
+                    if (pos < 0) {
+                        seen.mark(id, stamp, static_cast<int>(elements.size()));
                         elements.emplace_back(static_cast<int>(t->factor), id);
-                    else
-                        it->factor += static_cast<int>(t->factor);
+                    } else
+                        elements[static_cast<size_t>(pos)].factor += static_cast<int>(t->factor);
                     first = false;
                 }
                 if (first)
@@ -495,6 +520,63 @@ make_problem(const context& /*ctx*/, std::istream& is) noexcept
     }
 }
 
+namespace {
+
+// OR-Library set-covering format (scp4x .. scpnrh, scpclr, ...): `m n`, the n
+// column costs, then per row the number of columns covering it followed by
+// their 1-based indices.  The reference reads such instances only after they
+// have been rewritten as CPLEX-LP files (benchmarks/download.sh); this reads
+// them as they are, in one pass over the numbers: min sum c_j x_j, every row
+// sum_{j covers i} x_j >= 1, x binary (variables x1 .. xn, constraints r1 .. rm).
+raw_problem
+read_scp(std::istream& is)
+{
+    using tag = file_format_error_tag;
+    raw_problem pb;
+    pb.strings = std::make_shared<string_buffer>();
+    pb.type = objective_function_type::minimize;
+    long m = 0, n = 0;
+    if (!(is >> m >> n) || m <= 0 || n <= 0 || m > 0x7fffffffL || n > 0x7fffffffL)
+        return raw_problem(tag::bad_objective);
+    pb.vars.names.reserve(static_cast<size_t>(n));
+    pb.vars.values.reserve(static_cast<size_t>(n));
+    pb.objective.elements.reserve(static_cast<size_t>(n));
+    for (long j = 0; j != n; ++j) {
+        double c;
+        if (!(is >> c))
+            return raw_problem(tag::bad_objective);
+        pb.vars.names.emplace_back(pb.strings->append("x" + std::to_string(j + 1)));
+        pb.vars.values.emplace_back(0, 1, variable_type::binary);
+        pb.objective.elements.emplace_back(c, static_cast<int>(j));
+    }
+    pb.greater_constraints.reserve(static_cast<size_t>(m));
+    for (long i = 0; i != m; ++i) {
+        long k;
+        if (!(is >> k) || k <= 0 || k > n)
+            return raw_problem(tag::bad_constraint);
+        std::vector<function_element> elements;
+        elements.reserve(static_cast<size_t>(k));
+        for (long t = 0; t != k; ++t) {
+            long j;
+            if (!(is >> j) || j < 1 || j > n)
+                return raw_problem(tag::bad_constraint);
+            elements.emplace_back(1, static_cast<int>(j - 1));
+        }
+        pb.greater_constraints.emplace_back(pb.strings->append("r" + std::to_string(i + 1)),
+                                            std::move(elements), 1, static_cast<int>(i));
+    }
+    return pb;
+}
+
+bool
+ends_with(const std::string& s, const char* suffix)
+{
+    const std::string t(suffix);
+    return s.size() >= t.size() && s.compare(s.size() - t.size(), t.size(), t) == 0;
+}
+
+} // namespace
+
 raw_problem
 make_problem(const context_ptr& ctx, const std::string& filename)
 {
@@ -503,6 +585,13 @@ make_problem(const context_ptr& ctx, const std::string& filename)
     std::ifstream ifs(filename);
     if (!ifs.is_open())
         return raw_problem(file_format_error_tag::file_not_found);
+    if (ends_with(filename, ".scp")) {
+        try {
+            return read_scp(ifs);
+        } catch (...) {
+            return raw_problem(file_format_error_tag::bad_end_of_file);
+        }
+    }
     return make_problem(*ctx, ifs);
 }
 

@@ -344,3 +344,19 @@ def write_lp(inst: Instance, path: str) -> None:
         for i in range(0, inst.n, 16):
             f.write(" " + " ".join(names[i : i + 16]) + "\n")
         f.write("end\n")
+
+
+def write_scp(inst: Instance, path: str) -> None:
+    """Write a set-covering Instance in OR-Library's scp format (`m n`, the
+    costs, then per row its length and 1-based column indices)."""
+    assert inst.kind == 1 and not inst.maximize and np.all(inst.factor == 1)
+    with open(path, "w") as f:
+        f.write(f" {inst.m} {inst.n}\n")
+        c = inst.dense_costs()
+        for i in range(0, inst.n, 12):
+            f.write(" " + " ".join(f"{v:.17g}" for v in c[i:i + 12]) + "\n")
+        for k in range(inst.m):
+            cols = inst.col[inst.row_ptr[k]:inst.row_ptr[k + 1]] + 1
+            f.write(f" {len(cols)}\n")
+            for i in range(0, len(cols), 12):
+                f.write(" " + " ".join(str(int(v)) for v in cols[i:i + 12]) + "\n")
