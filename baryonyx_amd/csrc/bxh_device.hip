@@ -749,6 +749,8 @@ bxh_create(const bxh_problem* pb,
     h->version = 1;
     h->lds_bytes = static_cast<size_t>(lp.total);
     h->threads = std::min(1024, std::max(64, bxh::next_pow2(rmax)));
+    if (const char* et = std::getenv("BXH_V1_THREADS")) // experiments: the one-workgroup kernels' size
+        h->threads = std::max(64, std::min(1024, std::atoi(et) & ~63));
     // ---- inequalities-Z: sub-solver of every row (inequalities-Z.cpp:125-187)
     //      and the feasible patterns of the exhaustive rows
     //      (exhaustive-solver.hpp:111-167) --------------------------------------
@@ -825,6 +827,7 @@ bxh_create(const bxh_problem* pb,
             return fail(BXH_ERR_UNSUPPORTED, "instance does not fit the Z kernel's LDS plan");
         h->version = 3;
         h->lds_bytes = static_cast<size_t>(zl);
+        h->threads = std::min(h->threads, 256); // sweep_kernel_z's launch bound (longer rows loop)
     }
     if (v2_ok) {
         const int np = cmax <= 64 ? 4 : (cmax <= 80 ? 5 : (cmax <= 96 ? 6 : 8));

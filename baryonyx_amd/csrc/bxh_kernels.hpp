@@ -1770,7 +1770,7 @@ bb_search(const Float* val_s,
 // push_and_run around compute_update_row / push_and_compute_update_row of
 // itm-solver-inequalities-Z.cpp:441-564 (one workgroup per instance).
 template<typename Float>
-__global__ __launch_bounds__(1024) void
+__global__ __launch_bounds__(256) void // (256 threads at most: the cached column slots want registers)
 sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1890,6 +1890,9 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     RowZ nxt = { 0, 0, 0, 0, 0, 0, 0.0 };
     if (nrows > 0)
         nxt = row_of(0);
+    bool pre_ok = false; // the lane's element descriptor of the next row is in registers
+    int2 pre_cs = make_int2(0, 0);
+    int pre_j = 0, pre_pe = 0, pre_f = 0;
     for (int it = 0; it < nrows; ++it) {
         const RowZ cur = nxt;
         if (it + 1 < nrows)
@@ -1900,20 +1903,121 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         const int zk = cur.zk;
 
         // ---- decrease_preference + compute_reduced_costs (+ push) ----------
-        for (int idx = tid; idx < r; idx += T) {
-            // three independent loads from e (no chase through the column id)
-            const int e = rs + idx;
-            const int2 cs = pb.row_cs[e];
-            const int j = pb.row_col[e];
-            const int pe = pb.row_pos[e];
-            const int padlen = cs.y & 0xffff;
-            desc_s[idx] = make_int4(cs.x, padlen, pe, j);
-            res_s[idx] = pb.fac32[e]; // factor by row-local id (res_s is free until the sub-solvers)
-            Float v = column_rc(j, cs.x, padlen, pe, P[pe] * theta);
-            if (push) // :467-469: the true column
-                v += obj_amp * cost_x<Float>(pb, x_s, j, cost[j]);
-            val_s[idx] = v;
+        // A row that fits the workgroup, linear objective: lane = row element.
+        // The first 16 slots of the lane's column (all of it for columns of up
+        // to 16 entries) are fetched in ONE batch -- P, |a|, row -- and kept in
+        // registers: the repair pass of local_affect walks the same column again
+        // and nothing in it has changed by then but pi_k and the row's own P
+        // entry, so it needs no second trip to memory.  (The descriptor of the
+        // lane's element was fetched while the previous row was worked on.)
+        const bool fastrow = pb.q_ptr == nullptr && r <= T;
+        Float c_p[16];
+        int c_f[16], c_r[16];
+        int4 c_desc = make_int4(0, 0, 0, 0);
+        Float c_cost = 0;
+        if (fastrow) {
+            if (tid < r) {
+                const int e = rs + tid;
+                int2 cs;
+                int j, pe, fe;
+                if (pre_ok) { // prefetched a row ago
+                    cs = pre_cs;
+                    j = pre_j;
+                    pe = pre_pe;
+                    fe = pre_f;
+                } else {
+                    cs = pb.row_cs[e];
+                    j = pb.row_col[e];
+                    pe = pb.row_pos[e];
+                    fe = pb.fac32[e];
+                }
+                const int padlen = cs.y & 0xffff;
+                c_desc = make_int4(cs.x, padlen, pe, j);
+                desc_s[tid] = c_desc;
+                res_s[tid] = fe;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    c_p[u] = P[cs.x + u];
+                    c_f[u] = pb.col_fac[cs.x + u];
+                    c_r[u] = pb.col_row[cs.x + u];
+                }
+                c_cost = cost[j];
+            }
         }
+        // the next row's descriptors: on their way while this row is worked on
+        pre_ok = false;
+        if (it + 1 < nrows && pb.q_ptr == nullptr && nxt.re - nxt.rs <= T) {
+            pre_ok = true;
+            if (tid < nxt.re - nxt.rs) {
+                const int e = nxt.rs + tid;
+                pre_cs = pb.row_cs[e];
+                pre_j = pb.row_col[e];
+                pre_pe = pb.row_pos[e];
+                pre_f = pb.fac32[e];
+            }
+        }
+        // sum over the lane's column with `pown` for the row's own entry: the
+        // cached slots first, then (columns of more than 16 entries) the rest
+        auto cached_rc = [&](Float pown) -> Float {
+            Float acc = 0;
+            const int q0 = c_desc.x, pe = c_desc.z;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const Float pp = q0 + u == pe ? pown : c_p[u];
+                const int ri = c_r[u] < pb.m ? c_r[u] : 0; // padding: any finite pi
+                acc += (Float)c_f[u] * (pi_s[ri] + pp);
+            }
+            for (int qb = q0 + 16; qb < q0 + c_desc.y; qb += 8) {
+                Float p8[8];
+                int f8[8], r8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    p8[u] = P[qb + u];
+                    f8[u] = pb.col_fac[qb + u];
+                    r8[u] = pb.col_row[qb + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const Float pp = qb + u == pe ? pown : p8[u];
+                    const int ri = r8[u] < pb.m ? r8[u] : 0;
+                    acc += (Float)f8[u] * (pi_s[ri] + pp);
+                }
+            }
+            return c_cost - acc;
+        };
+        auto cached_own = [&]() -> Float { // P[pe] as it stands in memory
+            const int off = c_desc.z - c_desc.x;
+            Float v = 0;
+            if (off < 16) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    v = u == off ? c_p[u] : v;
+            } else
+                v = P[c_desc.z];
+            return v;
+        };
+        if (fastrow) {
+            if (tid < r) {
+                Float v = cached_rc(cached_own() * theta);
+                if (push) // :467-469: the true column
+                    v += obj_amp * c_cost;
+                val_s[tid] = v;
+            }
+        } else
+            for (int idx = tid; idx < r; idx += T) {
+                // three independent loads from e (no chase through the column id)
+                const int e = rs + idx;
+                const int2 cs = pb.row_cs[e];
+                const int j = pb.row_col[e];
+                const int pe = pb.row_pos[e];
+                const int padlen = cs.y & 0xffff;
+                desc_s[idx] = make_int4(cs.x, padlen, pe, j);
+                res_s[idx] = pb.fac32[e]; // factor by row-local id (res_s is free until the sub-solvers)
+                Float v = column_rc(j, cs.x, padlen, pe, P[pe] * theta);
+                if (push) // :467-469: the true column
+                    v += obj_amp * cost_x<Float>(pb, x_s, j, cost[j]);
+                val_s[idx] = v;
+            }
         const int n2 = next_pow2(r < 2 ? 2 : r);
         if (tid == 0)
             misc_s[MS_TIE] = 0;
@@ -2204,7 +2308,37 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
 
         BXH_STAMP(5);
         // ---- every variable: x, P, then its repaired preference ------------
-        {
+        if (fastrow) {
+            // by row element (the lane that holds the column's slots): its
+            // position in R comes from the inverse of the sorted order
+            const int sel = misc_s[MS_SEL];
+            const Float d = *d_s;
+            int* pos_s = (int*)key_run; // (free since the sort)
+            if (tid < r)
+                pos_s[id_s[tid]] = tid;
+            __syncthreads();
+            if (tid < r) {
+                const int i = pos_s[tid];
+                const int j = c_desc.w;
+                const int pe = c_desc.z;
+                const bool up = sel < 0 ? false : (sel + 1 >= r ? true : i <= sel);
+                Float p = cached_own() * theta;
+                if (up) {
+                    atomicOr(&x_s[j >> 5], 1u << (j & 31));
+                    p = p + d;
+                    const Float repair = cached_rc(p);
+                    if (repair >= 0)
+                        p = p - repair + d;
+                } else {
+                    atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
+                    p = p - d;
+                    const Float repair = cached_rc(p);
+                    if (repair <= 0)
+                        p = p + repair - d;
+                }
+                P[pe] = p;
+            }
+        } else {
             const int sel = misc_s[MS_SEL];
             const Float d = *d_s;
             // with a quadratic objective c(j, x) of a later variable sees the

@@ -1,5 +1,5 @@
 import ctypes as C, os, sys, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from baryonyx_amd import _ffi, synth
 from baryonyx_amd.driver import compute_delta, normalize_costs
 _ffi.LIB_PATH = os.path.join(_ffi.CSRC, "libbxh_prof.so")
