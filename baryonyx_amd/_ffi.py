@@ -30,7 +30,7 @@ BXH_ERR_DEVICE = -4
 # every symbol include/bxh.h declares (tests check the library exports them)
 SYMBOLS = [
     "bxh_last_error", "bxh_create", "bxh_create_device", "bxh_destroy", "bxh_set_stream", "bxh_batch",
-    "bxh_nwords", "bxh_rmax", "bxh_kernel_form", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_set_pi", "bxh_get_pi",
+    "bxh_nwords", "bxh_rmax", "bxh_kernel_form", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_get_x_all", "bxh_set_rng_all", "bxh_set_pi", "bxh_get_pi",
     "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset", "bxh_reset_all",
     "bxh_order_create", "bxh_order_init", "bxh_order_init_masked", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
     "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time",
@@ -148,6 +148,8 @@ def lib():
         L.bxh_set_x.argtypes = [C.c_void_p, C.c_int, u64p]
         L.bxh_get_x.argtypes = [C.c_void_p, C.c_int, u64p]
         L.bxh_set_x_all.argtypes = [C.c_void_p, u64p]
+        L.bxh_get_x_all.argtypes = [C.c_void_p, u64p]
+        L.bxh_set_rng_all.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         for nm in ("bxh_set_pi", "bxh_get_pi", "bxh_set_P", "bxh_get_P"):
             getattr(L, nm).argtypes = [C.c_void_p, C.c_int, f64p]
         L.bxh_set_rng.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
@@ -312,6 +314,16 @@ class DeviceBatch:
         v = np.zeros(self.nnz, np.float64)
         _check(self.L.bxh_get_P(self.h, i, _p(v, f64p)))
         return v
+
+    def get_x_all(self):
+        w = np.zeros((self.batch, self.nwords), np.uint64)
+        _check(self.L.bxh_get_x_all(self.h, _p(w, u64p)))
+        return w
+
+    def set_rng_all(self, states):
+        s = np.ascontiguousarray(states, np.uint32)
+        assert s.shape == (self.batch,)
+        _check(self.L.bxh_set_rng_all(self.h, s.ctypes.data_as(C.POINTER(C.c_uint32))))
 
     def set_rng(self, i, s):
         _check(self.L.bxh_set_rng(self.h, i, int(s)))

@@ -88,6 +88,10 @@ struct bxh_handle_s
     int romax = 0;             // longest per-owner part of a row
     int wide_g = 0;            // wide kernel (version 4): workgroups per instance
     bool device_built = false; // bxh_create_device: no host copy of the matrix exists
+    // 1: the instance's list R is known to be empty (a sweep over it is a no-op);
+    // 0: unknown or not empty.  Maintained by the calls that read `remaining` back.
+    std::vector<unsigned char> known_empty;
+    std::vector<unsigned char> skipped; // the instance's last sweep was such a no-op: nothing was launched
     DevBuf<double> stage_d;    // bxh_set_P / bxh_get_P of a device-built handle: one chunk
     unsigned epoch = 0;        // sweep launches so far (tags of the row exchange)
 
@@ -1710,6 +1714,34 @@ bxh_set_x_all(bxh_handle h, const uint64_t* words)
 }
 
 int
+bxh_get_x_all(bxh_handle h, uint64_t* words)
+{
+    if (!h || !words)
+        return fail(BXH_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(words, h->x.p, static_cast<size_t>(h->batch) * h->nwords * 8,
+                      hipMemcpyDeviceToHost));
+    return BXH_OK;
+}
+
+int
+bxh_set_rng_all(bxh_handle h, const uint32_t* state)
+{
+    if (!h || !state)
+        return fail(BXH_ERR_INVALID, "null argument");
+    for (int b = 0; b != h->batch; ++b)
+        if (state[b] == 0 || state[b] >= 2147483647u)
+            return fail(BXH_ERR_INVALID, "minstd_rand0 state must be in [1, 2^31-2]");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // (the engine state is a field of the per-instance status block)
+    HIP_TRY(hipMemcpy2D(&h->status.p[0].rng, sizeof(bxh::DevStatus), state, sizeof(uint32_t),
+                        sizeof(uint32_t), static_cast<size_t>(h->batch), hipMemcpyHostToDevice));
+    return BXH_OK;
+}
+
+int
 bxh_set_pi(bxh_handle h, int inst, const double* v)
 {
     if (int rc = check_inst(h, inst))
@@ -1866,6 +1898,8 @@ bxh_order_create(bxh_handle h, int order)
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->policy = order;
     h->use_cycle = order == BXH_ORDER_CYCLE;
+    h->known_empty.assign(static_cast<size_t>(h->batch), 0);
+    h->skipped.assign(static_cast<size_t>(h->batch), 0);
     std::fill(h->ostate.begin(), h->ostate.end(), h->use_cycle ? BXH_ORDER_NONE : order);
     const size_t B = static_cast<size_t>(h->batch), LC = static_cast<size_t>(h->lcap);
     HIP_TRY(hipMemset(h->mlist.p, 0, B * LC * sizeof(int2)));
@@ -1885,6 +1919,13 @@ bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* r
         if (int rc = bxh_order_create(h, order))
             return rc;
     HIP_TRY(hipSetDevice(h->device));
+    h->known_empty.resize(static_cast<size_t>(h->batch), 0);
+    h->skipped.resize(static_cast<size_t>(h->batch), 0);
+    for (int b = 0; b != h->batch; ++b)
+        if (!active || active[b]) {
+            h->known_empty[static_cast<size_t>(b)] = 0;
+            h->skipped[static_cast<size_t>(b)] = 0;
+        }
     // (the device copy of the per-instance orders is current: it is written
     // by bxh_order_create and by every sweep)
     const unsigned char* dev_active = nullptr;
@@ -1910,8 +1951,11 @@ bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* r
             HIP_TRY(hipMemcpy(h->h_status, h->status.p,
                               static_cast<size_t>(h->batch) * sizeof(bxh::DevStatus),
                               hipMemcpyDeviceToHost));
-            for (int b = 0; b != h->batch; ++b)
+            for (int b = 0; b != h->batch; ++b) {
                 remaining[b] = h->h_status[b].remaining;
+                h->known_empty[static_cast<size_t>(b)] =
+                  h->h_status[b].remaining == 0 && h->ostate[static_cast<size_t>(b)] <= BXH_ORDER_RANDOM_SORTING;
+            }
         }
         return BXH_OK;
     }
@@ -1954,8 +1998,11 @@ bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* r
         HIP_TRY(hipMemcpy(h->h_status, h->status.p,
                           static_cast<size_t>(h->batch) * sizeof(bxh::DevStatus),
                           hipMemcpyDeviceToHost));
-        for (int b = 0; b != h->batch; ++b)
+        for (int b = 0; b != h->batch; ++b) {
             remaining[b] = h->h_status[b].remaining;
+            h->known_empty[static_cast<size_t>(b)] =
+              h->h_status[b].remaining == 0 && h->ostate[static_cast<size_t>(b)] <= BXH_ORDER_RANDOM_SORTING;
+        }
     }
     return BXH_OK;
 }
@@ -2039,6 +2086,28 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
             st = st + 1 >= BXH_ORDER_CYCLE ? 0 : st + 1;
         need_prep = need_prep || (st >= BXH_ORDER_INFEASIBILITY_DECR && st <= BXH_ORDER_LAGRANGIAN_INCR);
         need_post = need_post || st == BXH_ORDER_INFEASIBILITY_DECR || st == BXH_ORDER_INFEASIBILITY_INCR;
+    }
+    // A sweep over an empty list R changes nothing (compute_order::run walks no
+    // row and finds the same empty list again): when that is known of every
+    // active instance -- the steady state of optimize()'s push phases -- nothing
+    // is launched.
+    {
+        h->known_empty.resize(static_cast<size_t>(h->batch), 0);
+        h->skipped.resize(static_cast<size_t>(h->batch), 0);
+        bool all_empty = !std::getenv("BXH_NO_SKIP");
+        for (int b = 0; b != h->batch && all_empty; ++b)
+            if ((!a->active || a->active[b]) &&
+                !(h->known_empty[static_cast<size_t>(b)] &&
+                  h->ostate[static_cast<size_t>(b)] <= BXH_ORDER_RANDOM_SORTING))
+                all_empty = false;
+        for (int b = 0; b != h->batch; ++b)
+            if (!a->active || a->active[b]) {
+                h->skipped[static_cast<size_t>(b)] = all_empty ? 1 : 0;
+                if (!all_empty)
+                    h->known_empty[static_cast<size_t>(b)] = 0; // until the outcome is read back
+            }
+        if (all_empty)
+            return BXH_OK;
     }
     std::memcpy(h->h_order, h->ostate.data(), static_cast<size_t>(h->batch) * sizeof(int));
     HIP_TRY(hipMemcpyAsync(h->order_b.p, h->h_order, static_cast<size_t>(h->batch) * sizeof(int),
@@ -2126,6 +2195,17 @@ bxh_status_sync(bxh_handle h, bxh_status* out)
             return fail(BXH_ERR_DEVICE,
                         "a workgroup timed out waiting for its partners (the "
                         "cooperating workgroups were not all resident)");
+    }
+    h->known_empty.resize(static_cast<size_t>(h->batch), 0);
+    h->skipped.resize(static_cast<size_t>(h->batch), 0);
+    for (int b = 0; b != h->batch; ++b) {
+        if (h->skipped[static_cast<size_t>(b)]) { // its last sweep was the no-op that was not launched
+            h->h_status[b].pi_changed = 0;
+            h->h_status[b].rows_in_sweep = 0;
+        }
+        h->known_empty[static_cast<size_t>(b)] =
+          h->h_status[b].remaining == 0 && static_cast<size_t>(b) < h->ostate.size() &&
+          h->ostate[static_cast<size_t>(b)] <= BXH_ORDER_RANDOM_SORTING;
     }
     if (out) {
         static_assert(sizeof(bxh_status) == sizeof(bxh::DevStatus), "ABI");

@@ -453,6 +453,10 @@ struct device_batch
         check(bxh_sweep_async(h, &a));
     }
     void sync() { check(bxh_status_sync(h, status.data())); }
+    // x / engine state of every instance in one transfer
+    void get_x_all(std::uint64_t* words) { check(bxh_get_x_all(h, words)); }
+    void set_x_all(const std::uint64_t* words) { check(bxh_set_x_all(h, words)); }
+    void set_rng_all(const std::uint32_t* states) { check(bxh_set_rng_all(h, states)); }
 };
 
 // The worker pool of optimize() over several devices: worker b lives on device
@@ -508,10 +512,58 @@ struct device_pool
         for (int b = 0; b != workers; ++b)
             at.push_back(ref{ dev[static_cast<size_t>(b % D)].get(), b / D });
         m = dev[0]->m;
+        init_mirrors();
     }
-    void set_x(int b, const bit_array& x) { at[b].d->set_x(at[b].i, x); }
-    void get_x(int b, bit_array& x) { at[b].d->get_x(at[b].i, x); }
-    void set_rng(int b, const random_engine& e) { at[b].d->set_rng(at[b].i, e); }
+    // Host mirrors of every instance's x and engine state, one block per device:
+    // a round of optimize() moves them with ONE transfer per device and direction
+    // instead of one per worker (64 synchronising copies per round otherwise).
+    std::vector<std::vector<std::uint64_t>> xmirror; // [device][batch * nwords]
+    std::vector<std::vector<std::uint32_t>> rmirror; // [device][batch]
+    std::vector<char> x_dirty, rng_dirty, launched;  // per device
+    int dev_of(int b) const { return b % static_cast<int>(dev.size()); }
+    void init_mirrors()
+    {
+        const size_t D = dev.size();
+        xmirror.resize(D);
+        rmirror.resize(D);
+        x_dirty.assign(D, 0);
+        rng_dirty.assign(D, 0);
+        launched.assign(D, 0);
+        for (size_t d = 0; d != D; ++d) {
+            xmirror[d].assign(static_cast<size_t>(dev[d]->batch) * dev[d]->nwords, 0);
+            rmirror[d].assign(static_cast<size_t>(dev[d]->batch), 1u);
+        }
+    }
+    void set_x(int b, const bit_array& x)
+    {
+        const int d = dev_of(b);
+        std::copy(x.w.begin(), x.w.end(),
+                  xmirror[d].begin() + static_cast<size_t>(at[b].i) * dev[d]->nwords);
+        x_dirty[d] = 1;
+    }
+    void get_x(int b, bit_array& x) const
+    {
+        const int d = dev_of(b);
+        const auto* src = xmirror[d].data() + static_cast<size_t>(at[b].i) * dev[d]->nwords;
+        std::copy(src, src + x.w.size(), x.w.begin());
+    }
+    void set_rng(int b, const random_engine& e)
+    {
+        const int d = dev_of(b);
+        rmirror[d][static_cast<size_t>(at[b].i)] = engine_state(e);
+        rng_dirty[d] = 1;
+    }
+    // what the host changed since the last sweep goes to the devices
+    void flush()
+    {
+        for (size_t d = 0; d != dev.size(); ++d) {
+            if (x_dirty[d])
+                dev[d]->set_x_all(xmirror[d].data());
+            if (rng_dirty[d])
+                dev[d]->set_rng_all(rmirror[d].data());
+            x_dirty[d] = rng_dirty[d] = 0;
+        }
+    }
     void order_create(int order)
     {
         for (auto& d : dev)
@@ -519,6 +571,7 @@ struct device_pool
     }
     void order_init(int order, const std::vector<std::uint8_t>* mask)
     {
+        flush(); // compute_order::init reads the x the restarts just wrote
         const int D = static_cast<int>(dev.size());
         for (int d = 0; d != D; ++d) {
             std::vector<std::uint8_t> local(static_cast<size_t>(dev[d]->batch), 0);
@@ -534,18 +587,33 @@ struct device_pool
     // one sweep of the active workers on every device (launched on all, then awaited)
     void sweep_async(double delta, double theta, bool push, double obj_amp, int order)
     {
-        for (auto& d : dev) {
+        flush();
+        for (size_t d = 0; d != dev.size(); ++d) {
             bool any = false;
-            for (auto a : d->active)
+            for (auto a : dev[d]->active)
                 any = any || a;
-            if (any)
-                d->sweep_async(delta, theta, push, obj_amp, order);
+            if (any) {
+                dev[d]->sweep_async(delta, theta, push, obj_amp, order);
+                launched[d] = 1;
+            }
         }
     }
+    // outcome of the sweeps: the status blocks, and x / the engines into the mirrors
     void sync()
     {
-        for (auto& d : dev)
-            d->sync();
+        for (size_t d = 0; d != dev.size(); ++d) {
+            dev[d]->sync();
+            if (launched[d]) {
+                bool moved = false; // (a sweep over empty lists is not even launched)
+                for (int i = 0; i != dev[d]->batch; ++i)
+                    moved = moved || dev[d]->status[i].rows_in_sweep != 0;
+                if (moved)
+                    dev[d]->get_x_all(xmirror[d].data());
+                launched[d] = 0;
+            }
+            for (int i = 0; i != dev[d]->batch; ++i)
+                rmirror[d][static_cast<size_t>(i)] = dev[d]->status[i].rng;
+        }
     }
 };
 
@@ -1086,6 +1154,8 @@ optimize_problem(const context& ctx, const problem& pb)
         int best_remaining = INT_MAX;
         long calls = 0;
         phase_t phase = PH_REINIT;
+        double value = 0.0;    // objective of x, valid while value_ok
+        bool value_ok = false;
     };
     std::vector<worker> wk(static_cast<size_t>(workers));
     for (auto& w : wk)
@@ -1132,6 +1202,7 @@ optimize_problem(const context& ctx, const problem& pb)
                 continue;
             init_mask[static_cast<size_t>(b)] = 1;
             ++w.calls;
+            w.value_ok = false;
             w.kappa_start = static_cast<Float>(best_recorder.reinit(lctx[b], b, p, w.x));
             w.kappa = w.kappa_start;
             w.best_remaining = INT_MAX;
@@ -1172,9 +1243,17 @@ optimize_problem(const context& ctx, const problem& pb)
             worker& w = wk[b];
             const int remaining = slv.status[b].remaining;
             set_engine_state(lctx[b].rng, slv.status[b].rng);
+            // (a sweep that updated no row left x as it was: its objective value,
+            // n additions, is still the one computed for the sweep before)
+            if (slv.status[b].rows_in_sweep != 0)
+                w.value_ok = false;
             auto update = [&](long loop) {
-                slv.get_x(b, w.x);
-                best_recorder.try_update(lctx[b], w.x, cost.results(w.x, cost_constant), loop);
+                if (!w.value_ok) {
+                    slv.get_x(b, w.x);
+                    w.value = cost.results(w.x, cost_constant);
+                    w.value_ok = true;
+                }
+                best_recorder.try_update(lctx[b], w.x, w.value, loop);
             };
             switch (w.phase) {
             case PH_MAIN: // :668-700

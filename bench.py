@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="wall budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--e2e-rounds", type=int, default=100,
+                    help="rounds of the end-to-end baryonyx::optimize run next to the oracle's (0 = skip)")
     return ap.parse_args()
 
 
@@ -443,6 +445,59 @@ class StdWorkload:
         return cpu_baseline(self.inst, self.params, float_type, seconds, threads)
 
 
+def end_to_end(inst, float_type, rounds, threads):
+    """baryonyx::optimize (C++ host library, every sweep a launch + a status
+    read-back) for a fixed number of rounds on this instance, next to the
+    oracle's optimize() under the same deterministic schedule: objective at an
+    equal sweep budget (identical by construction: tests/test_gpu_optimize.py)
+    and the time both take.  The CPU figure is the CPU time the oracle's workers
+    spend inside their sweeps divided by the cores they could run on (the
+    reference's workers run freely; the oracle's lock-step conductor is test
+    scaffolding and is not charged)."""
+    import tempfile
+
+    from baryonyx_amd import host_ffi as H
+    from baryonyx_amd import synth
+    from oracle import oracle_ffi as O
+
+    workers = 64
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "instance.scp")
+        synth.write_scp(inst, path)
+        minst = H.merged(path)
+        hp = H.default_params(seed=20260101, thread=workers, float_type=float_type, sweep_budget=rounds,
+                              time_limit=3600.0)
+        H.optimize_trace(path, H.default_params(seed=1, thread=workers, float_type=float_type,
+                                                sweep_budget=2, time_limit=3600.0), minst.n)  # warm-up
+        t0 = time.perf_counter()
+        res, tr = H.optimize_trace(path, hp, minst.n)
+        gpu_s = time.perf_counter() - t0
+    okw = {k: getattr(hp, k) for k in (
+        "theta delta kappa_min kappa_step kappa_max alpha pushing_k_factor "
+        "pushing_objective_amplifier init_policy_random w limit seed pushes_limit "
+        "pushing_iteration_limit init_population_size order init_policy cost_norm").split()}
+    t0 = time.perf_counter()
+    ores, otr = O.optimize(minst, float_type, O.default_params(sort_mode=1, **okw), thread=workers,
+                           rounds=rounds)
+    cpu_wall = time.perf_counter() - t0
+    cores = threads if threads > 0 else usable_cores()
+    return {
+        "what": f"baryonyx::optimize, {workers} workers, {rounds} rounds of one sweep each "
+                f"(restarts, crossover / mutation, push phases as the reference schedules them)",
+        "rounds": rounds,
+        "gpu_seconds": gpu_s,
+        "cpu_seconds": otr["sweep_seconds"] / min(cores, workers),
+        "cpu_cores": min(cores, workers),
+        "cpu_sweep_cpu_seconds": otr["sweep_seconds"],
+        "cpu_wall_seconds_lockstep": cpu_wall,
+        "objective_at_budget": {"gpu": res.value if res.status == 0 else None,
+                                "cpu": ores.value if ores.status == 0 else None},
+        "identical_population": bool(np.array_equal(tr["pop_hash"], otr["pop_hash"])
+                                     and np.array_equal(tr["worker_rng"], otr["worker_rng"])),
+        "row_updates": int(ores.row_updates),
+    }
+
+
 def spawn_ranks(n):
     """`bench.py --gpus N` outside a launcher: start the N ranks as children
     (before this process touches the GPU) and pass rank 0's line through."""
@@ -579,8 +634,11 @@ def main():
                                                   mean_row_bytes)
         elif args.cpu_seconds > 0:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
     dev.close()
+    if rank == 0:
+        if args.e2e_rounds > 0 and world == 1 and args.config != "c4":
+            out["end_to_end"] = end_to_end(wl.inst, float_type, args.e2e_rounds, args.cpu_threads)
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

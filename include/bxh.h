@@ -179,6 +179,11 @@ int bxh_get_x(bxh_handle h, int inst, uint64_t* words);
  * restart loop does between two runs: reinit writes x,
  * itm-optimizer-common.hpp:660-663); host or device memory */
 int bxh_set_x_all(bxh_handle h, const uint64_t* words_batch);
+/* x / the engine state of every instance in one transfer each ([batch][nwords],
+ * [batch]): what optimize()'s bookkeeping reads and writes once per round for
+ * its whole worker pool */
+int bxh_get_x_all(bxh_handle h, uint64_t* words_batch);
+int bxh_set_rng_all(bxh_handle h, const uint32_t* state_batch);
 int bxh_set_pi(bxh_handle h, int inst, const double* pi_m);
 int bxh_get_pi(bxh_handle h, int inst, double* pi_m);
 int bxh_set_P(bxh_handle h, int inst, const double* P_nnz);

@@ -28,6 +28,7 @@
 
 #include "itm_oracle.hpp"
 
+#include <ctime>
 #include <condition_variable>
 #include <mutex>
 #include <sstream>
@@ -338,6 +339,7 @@ public:
     explicit Conductor(int workers)
       : state(static_cast<size_t>(workers), RUNNING)
       , go(static_cast<size_t>(workers), 0)
+      , wcv(static_cast<size_t>(workers))
     {}
 
     // worker side: park at a gate until released; false = the run is over
@@ -345,8 +347,8 @@ public:
     {
         std::unique_lock<std::mutex> lk(mu);
         state[b] = g;
-        cv.notify_all();
-        cv.wait(lk, [&] { return go[b] != 0 || stop; });
+        cv.notify_one(); // (the conductor alone waits on cv)
+        wcv[b].wait(lk, [&] { return go[b] != 0 || stop; });
         if (!go[b])
             return false; // stopped while parked
         go[b] = 0;
@@ -357,7 +359,7 @@ public:
     {
         std::lock_guard<std::mutex> lk(mu);
         state[b] = EXITED;
-        cv.notify_all();
+        cv.notify_one();
     }
 
     // conductor side
@@ -375,13 +377,14 @@ public:
     {
         std::lock_guard<std::mutex> lk(mu);
         go[b] = 1;
-        cv.notify_all();
+        wcv[b].notify_one();
     }
     void finish()
     {
         std::lock_guard<std::mutex> lk(mu);
         stop = true;
-        cv.notify_all();
+        for (auto& c : wcv)
+            c.notify_one();
     }
 
     long run(long rounds)
@@ -416,6 +419,7 @@ private:
     std::condition_variable cv;
     std::vector<int> state;
     std::vector<int> go;
+    std::vector<std::condition_variable> wcv; // one per worker: no thundering herd
     bool stop = false;
 };
 
@@ -430,7 +434,16 @@ struct OptimizeResult
     std::vector<long> worker_calls;    // optimize_functor::m_call_number
     std::uint64_t row_updates = 0;
     long rounds = 0;
+    double sweep_seconds = 0.0; // CPU time inside compute.run / push_and_run, summed over the workers
 };
+
+inline double
+thread_cpu_seconds() // CPU time of the calling thread (not the time it waited for a core)
+{
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return static_cast<double>(ts.tv_sec) + 1e-9 * static_cast<double>(ts.tv_nsec);
+}
 
 inline unsigned
 engine_state_of(const random_engine& e)
@@ -455,7 +468,8 @@ optimize_worker(Conductor& cd,
                 int kind,
                 bool maximize,
                 const Params& p,
-                std::uint64_t& row_updates)
+                std::uint64_t& row_updates,
+                double& sweep_seconds)
 {
     const int variables = cs.n;
     BitArray x(variables);
@@ -478,9 +492,11 @@ optimize_worker(Conductor& cd,
     auto sweep = [&](Float kappa, bool push) -> int { // one compute.run / push_and_run
         if (!cd.arrive(b, Conductor::AT_SWEEP))
             return -1;
+        const double t0 = thread_cpu_seconds();
         const int remaining =
           push ? compute.run(slv, x, lc.rng, kappa, delta, theta, true, pushing_objective_amplifier)
                : compute.run(slv, x, lc.rng, kappa, delta, theta);
+        sweep_seconds += thread_cpu_seconds() - t0;
         row_updates = slv.row_updates;
         if (!cd.arrive(b, Conductor::AT_POST))
             return -1;
@@ -579,13 +595,14 @@ optimize(const Constraints& cs,
         lctx.emplace_back(std::make_unique<LocalContext>(p, static_cast<unsigned>(i), seeds[i]));
     std::vector<long> calls(static_cast<size_t>(thread), 0);
     std::vector<std::uint64_t> updates(static_cast<size_t>(thread), 0);
+    std::vector<double> seconds(static_cast<size_t>(thread), 0.0);
 
     Conductor cd(thread);
     std::vector<std::thread> pool;
     for (int i = 0; i != thread; ++i)
         pool.emplace_back([&, i] {
             optimize_worker<Float>(cd, i, *lctx[i], calls[i], best_recorder, cs, cost, cost_constant,
-                                   kind, maximize, p, updates[i]);
+                                   kind, maximize, p, updates[i], seconds[i]);
             cd.exited(i);
         });
     r.rounds = cd.run(rounds);
@@ -603,6 +620,7 @@ optimize(const Constraints& cs,
         r.worker_rng.push_back(engine_state_of(lctx[i]->rng));
         r.worker_calls.push_back(calls[i]);
         r.row_updates += updates[i];
+        r.sweep_seconds += seconds[i];
     }
     return r;
 }

@@ -554,7 +554,8 @@ orc_optimize(const orc_problem* pb,
              uint64_t* pop_hash,
              uint64_t* pop_x,
              uint32_t* worker_rng,
-             int64_t* worker_calls)
+             int64_t* worker_calls,
+             double* sweep_seconds)
 {
     try {
         orc::Constraints cs;
@@ -574,6 +575,8 @@ orc_optimize(const orc_problem* pb,
         out->loop = r.loop;
         out->row_updates = r.row_updates;
         out->sweeps = static_cast<uint64_t>(r.rounds);
+        if (sweep_seconds)
+            *sweep_seconds = r.sweep_seconds;
         const size_t nwords = static_cast<size_t>(cs.n / 64 + 1);
         for (size_t i = 0; i != r.population.size(); ++i) {
             if (pop_remaining)

@@ -143,7 +143,8 @@ int orc_optimize(const orc_problem* pb,
                  uint64_t* pop_hash,
                  uint64_t* pop_x,
                  uint32_t* worker_rng,
-                 int64_t* worker_calls);
+                 int64_t* worker_calls,
+                 double* sweep_seconds); /* time inside the sweeps, summed over the workers; may be NULL */
 
 /* Z sub-solvers on their own (lib/test/lib.cpp:376-563) */
 int orc_bb_solve(int maximize,

@@ -146,7 +146,7 @@ def lib():
         L.orc_optimize.argtypes = [
             C.POINTER(OrcProblem), C.c_int, C.c_int, C.c_int, C.POINTER(OrcParams), C.c_int,
             C.c_int64, C.POINTER(OrcResult), i32p, f64p, u64p, u64p,
-            C.POINTER(C.c_uint32), C.POINTER(C.c_int64),
+            C.POINTER(C.c_uint32), C.POINTER(C.c_int64), f64p,
         ]
         L.orc_optimize.restype = C.c_int
         L.orc_default_params.argtypes = [C.POINTER(OrcParams)]
@@ -364,14 +364,16 @@ def optimize(inst, float_type=1, params=None, thread=4, rounds=100, kind=None, m
         pop_hash=np.zeros(pop, np.uint64), pop_x=np.zeros((pop, nwords), np.uint64),
         worker_rng=np.zeros(thread, np.uint32), worker_calls=np.zeros(thread, np.int64),
     )
+    secs = np.zeros(1, np.float64)
     rc = L.orc_optimize(
         C.byref(pb.c), inst.kind if kind is None else kind, float_type,
         int(inst.maximize if maximize is None else maximize), C.byref(p), thread, rounds,
         C.byref(res), _p(out["pop_remaining"], i32p), _p(out["pop_value"], f64p),
         _p(out["pop_hash"], u64p), _p(out["pop_x"], u64p),
         out["worker_rng"].ctypes.data_as(C.POINTER(C.c_uint32)),
-        out["worker_calls"].ctypes.data_as(C.POINTER(C.c_int64)),
+        out["worker_calls"].ctypes.data_as(C.POINTER(C.c_int64)), _p(secs, f64p),
     )
     if rc != 0:
         raise RuntimeError(L.orc_last_error().decode())
+    out["sweep_seconds"] = float(secs[0])
     return res, out

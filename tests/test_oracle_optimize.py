@@ -36,7 +36,8 @@ def test_schedule_is_deterministic_and_population_is_consistent(oracle, maker, k
     assert (r1.status, r1.value, r1.loop, r1.remaining_constraints, r1.row_updates) == \
            (r2.status, r2.value, r2.loop, r2.remaining_constraints, r2.row_updates)
     for k in o1:
-        assert np.array_equal(o1[k], o2[k]), k
+        if k != "sweep_seconds":
+            assert np.array_equal(o1[k], o2[k]), k
     assert r1.sweeps == 250 and int(o1["worker_calls"].min()) >= 1
     # storage::sort (:424-442): by remaining constraints, then by value
     rem, val = o1["pop_remaining"], o1["pop_value"]
