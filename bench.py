@@ -201,11 +201,12 @@ def pmc_traffic(workload, float_type, form):
     best = None
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     for rnd in sorted(os.listdir(root)) if os.path.isdir(root) else []:
-        path = os.path.join(root, rnd, "pmc_traffic.json")
-        if os.path.isfile(path):
-            with open(path) as f:
+        for name in sorted(os.listdir(os.path.join(root, rnd))):
+            if not (name.startswith("pmc_traffic") and name.endswith(".json")):
+                continue
+            with open(os.path.join(root, rnd, name)) as f:
                 rec = json.load(f)
-            if (rec.get("workload") == workload and float_type == 1
+            if ((rec.get("workload") or "").split(":")[0] == workload.split(":")[0] and float_type == 1
                     and rec.get("kernel_form", 44) == form):
                 best = rec["traffic_bytes_per_launch"]
     return best

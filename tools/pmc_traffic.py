@@ -6,7 +6,7 @@
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out/f -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out/w -- python3 bench.py ...
     python3 tools/pmc_traffic.py out/f/*/*_counter_collection.csv out/w/*/*_counter_collection.csv \
-        "<config.workload of the bench line>" > profiles/rNN/pmc_traffic.json
+        "<config.workload of the bench line>" [kernel form, bxh_kernel_form()] > profiles/rNN/pmc_traffic[_cfg].json
 
 Units and corrections follow MI355X_MICROARCH.md (HBM): both counters are in
 KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B per lane)
@@ -33,7 +33,8 @@ def main():
     f_kib, w_kib = statistics.median(fetch), statistics.median(write)
     out = {
         "workload": sys.argv[3] if len(sys.argv) > 3 else None,
-        "kernel": "bxh::sweep_kernel_v2",
+        "kernel": "bxh::sweep_kernel*",
+        "kernel_form": int(sys.argv[4]) if len(sys.argv) > 4 else 44,
         "launches_sampled": [len(fetch), len(write)],
         "FETCH_SIZE_KiB_per_launch": f_kib,
         "WRITE_SIZE_KiB_per_launch": w_kib,
