@@ -97,8 +97,7 @@ HIPCC_FLAGS = [
 def build(force: bool = False) -> str:
     """Compile csrc/bxh_device.hip for gfx950 into csrc/libbxh.so (in-tree, so
     it travels with the repository snapshot)."""
-    srcs = [os.path.join(CSRC, f) for f in ("bxh_device.hip", "bxh_kernels.hpp", "bxh_wide.hpp",
-                                          "bxh_wide_build.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
     srcs.append(os.path.join(_HERE, "..", "include", "bxh.h"))
     stale = force or not os.path.exists(LIB_PATH)
     if not stale:

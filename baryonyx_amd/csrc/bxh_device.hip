@@ -7,6 +7,7 @@
 #include "../../include/bxh.h"
 #include "bxh_kernels.hpp"
 #include "bxh_wide.hpp"
+#include "bxh_narrow.hpp"
 #include "bxh_wide_build.hpp"
 
 #include <algorithm>
@@ -87,6 +88,9 @@ struct bxh_handle_s
     int sw_chain = 0, sw_prod = 0; // v2: staging waves of the chain / a producer
     int romax = 0;             // longest per-owner part of a row
     int wide_g = 0;            // wide kernel (version 4): workgroups per instance
+    int narrow_ne = 0, narrow_npc = 0; // narrow kernel (version 5): elements per lane, prefetched pieces
+    DevBuf<int4> ndesc;        // narrow kernel: per CSR element descriptors
+    bxh::NarrowParams npar{};
     bool device_built = false; // bxh_create_device: no host copy of the matrix exists
     // 1: the instance's list R is known to be empty (a sweep over it is a no-op);
     // 0: unknown or not empty.  Maintained by the calls that read `remaining` back.
@@ -305,6 +309,29 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
 #undef BXH_V2
     } else if (h->version == 3) {
         BXH_LAUNCH((bxh::sweep_kernel_z<Float>));
+    } else if (h->version == 5) {
+#define BXH_NARROW(PM, NE, NPC)                                                \
+    hipLaunchKernelGGL((bxh::sweep_kernel_narrow<Float, PM, NE, NPC>), dim3(h->batch), dim3(64), \
+                       h->lds_bytes, h->stream, h->dp, h->ds, a, h->npar)
+#define BXH_NARROW_PM(PM)                                                      \
+    do {                                                                       \
+        if (h->narrow_ne == 1 && h->narrow_npc == 1)                           \
+            BXH_NARROW(PM, 1, 1);                                              \
+        else if (h->narrow_ne == 1)                                            \
+            BXH_NARROW(PM, 1, 2);                                              \
+        else if (h->narrow_ne == 2 && h->narrow_npc == 1)                      \
+            BXH_NARROW(PM, 2, 1);                                              \
+        else if (h->narrow_ne == 2)                                            \
+            BXH_NARROW(PM, 2, 2);                                              \
+        else                                                                   \
+            BXH_NARROW(PM, 4, 1);                                              \
+    } while (0)
+        if (pm1)
+            BXH_NARROW_PM(true);
+        else
+            BXH_NARROW_PM(false);
+#undef BXH_NARROW_PM
+#undef BXH_NARROW
     } else if (h->version == 4) {
         if (pm1)
             hipLaunchKernelGGL((bxh::sweep_kernel_wide<Float, true>), dim3(h->batch * h->wide_g),
@@ -450,7 +477,22 @@ bxh_create(const bxh_problem* pb,
                             "together (batch * workgroups per instance <= CUs)");
         }
     }
-    const bool v2_ok = !wide_g && !zsolver && cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
+    // Short rows (bxh_narrow.hpp): one wave per instance, several instances per
+    // CU.  Rows of at most 256 elements, columns of a few 16-entry pieces, linear
+    // objective, 01 / 101 solvers; BXH_NARROW=0 keeps the staged kernel, =1 takes
+    // the narrow one for any column length the staged kernel would take.
+    bool narrow = false;
+    {
+        const char* en = std::getenv("BXH_NARROW");
+        const bool asked = en && en[0] == '1';
+        const bool off = (en && en[0] == '0') || std::getenv("BXH_GROUPS") || (force_v1 && force_v1[0] == '1');
+        const int ne = rmax <= 64 ? 1 : (rmax <= 128 ? 2 : 4);
+        const int npc = (cmax <= 16 || ne == 4) ? 1 : 2;
+        const int nl = bxh::narrow_lds(m, n, h->nwords, rmax, float_type == BXH_FLOAT ? 4 : 8, ne, npc).total;
+        narrow = !wide_g && !zsolver && pb->n_quad == 0 && rmax <= 256 && cmax <= 128 && m < 32767 &&
+                 nl <= 160 * 1024 && !off && (asked || (cmax <= 32 && rmax <= 64));
+    }
+    const bool v2_ok = !narrow && !wide_g && !zsolver && cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
     int groups = 1;
     if (v2_ok) {
         int cus = 256;
@@ -888,6 +930,14 @@ bxh_create(const bxh_problem* pb,
         h->lds_bytes = static_cast<size_t>(wl.total);
         h->lds_bytes_init = 0;
     }
+    if (narrow) {
+        h->version = 5;
+        h->threads = 64;
+        h->narrow_ne = rmax <= 64 ? 1 : (rmax <= 128 ? 2 : 4);
+        h->narrow_npc = (cmax <= 16 || h->narrow_ne == 4) ? 1 : 2;
+        h->lds_bytes = static_cast<size_t>(
+          bxh::narrow_lds(m, n, h->nwords, rmax, static_cast<int>(h->fsize), h->narrow_ne, h->narrow_npc).total);
+    }
     if (std::getenv("BXH_DEBUG"))
         std::fprintf(stderr, "bxh: kernel v%d threads=%d lds=%zu np=%d groups=%d pipe=%d (chain %d, producer %d staging waves, lookahead %d)\n",
                      h->version, h->threads, h->lds_bytes, h->nb, groups, h->pipe, h->sw_chain,
@@ -975,6 +1025,28 @@ bxh_create(const bxh_problem* pb,
         else
             to_float<double>(dc.data(), dc.size(), c2);
         HIP_TRY(h->desc_cost.upload(c2));
+        if (narrow) {
+            std::vector<int4> nd(static_cast<size_t>(nnz) * 2);
+            for (int e = 0; e != nnz; ++e) {
+                const int j = pb->col[e];
+                const int neg = (pm1 && pb->factor && pb->factor[e] < 0) ? static_cast<int>(0x80000000u) : 0;
+                nd[2 * static_cast<size_t>(e)] = make_int4(col_start[j], col_len[j], row_pos[e], j | neg);
+                int lo = 0, hi = 0;
+                if (float_type == BXH_FLOAT) {
+                    const float cf = static_cast<float>(pb->cost[j]);
+                    std::memcpy(&lo, &cf, 4);
+                } else {
+                    const double cd = pb->cost[j];
+                    int w[2];
+                    std::memcpy(w, &cd, 8);
+                    lo = w[0];
+                    hi = w[1];
+                }
+                nd[2 * static_cast<size_t>(e) + 1] = make_int4(lo, hi, 0, 0);
+            }
+            HIP_TRY(h->ndesc.upload(nd));
+            h->npar.desc = h->ndesc.p;
+        }
     }
     h->h_row_pos = std::move(row_pos);
     h->h_row_ptr.assign(pb->row_ptr, pb->row_ptr + m + 1);
@@ -1109,6 +1181,22 @@ bxh_create(const bxh_problem* pb,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, wl));
     }
 
+    if (narrow && h->lds_bytes > 64 * 1024) {
+        const int nl = static_cast<int>(h->lds_bytes);
+#define BXH_SET_NARROW(F, PM)                                                  \
+    do {                                                                       \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
+    } while (0)
+        BXH_SET_NARROW(float, false);
+        BXH_SET_NARROW(float, true);
+        BXH_SET_NARROW(double, false);
+        BXH_SET_NARROW(double, true);
+#undef BXH_SET_NARROW
+    }
     // the kernels may ask for more than the 64 KiB default dynamic LDS
     if (!wide_g) {
         const int want = static_cast<int>(std::max(h->lds_bytes, h->lds_bytes_init));
@@ -1663,6 +1751,8 @@ bxh_kernel_form(bxh_handle h)
         return 3;
     if (h->version == 4)
         return 100 + h->wide_g;
+    if (h->version == 5)
+        return 5;
     if (h->version != 2)
         return 1;
     if (h->pipe)

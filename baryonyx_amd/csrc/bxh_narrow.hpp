@@ -1,0 +1,982 @@
+// baryonyx_amd/csrc/bxh_narrow.hpp -- short rows: one wavefront per Solver
+// instance, several instances per CU.
+//
+// The staged kernel (bxh_kernels.hpp, sweep_kernel_v2) spends a 512-thread
+// workgroup and most of a CU's LDS on one instance; on rows of 20..250
+// elements over columns of a dozen (OR-Library scp4x, the aa0x set-partitioning
+// shapes) its row time is barriers and memory round trips, not data.  Here a
+// row is ONE wave's job:
+//
+//   * lane l owns elements l, l + 64, ... of the row (NE per lane) and walks
+//     the whole column of each -- 16 padded CSC slots, one 128-byte line of P
+//     plus 32 bytes of row ids -- with the two sums of compute_reduced_costs in
+//     CSC order (itm-solver-inequalities-01.cpp:166-191; the order fixes the bits);
+//   * no workgroup barrier anywhere: the block IS the wave (s_barrier of a
+//     one-wave block is a no-op), reductions are DPP, the small sorts are the
+//     wave-level ones of bxh_kernels.hpp;
+//   * rows are software-pipelined through LDS: while row `it` is being decided,
+//     the column lines of row it+1 and the element descriptors of row it+2 are
+//     on their way, moved by LDS-DMA loads (global_load_lds_dwordx4: no
+//     registers, eight lanes per 128-byte line so that a load instruction
+//     touches 8 lines, not 64), into swizzled slots the owning lane then reads
+//     without bank conflicts;
+//   * the columns of row it+1 are read BEFORE row it stores its P values; the
+//     one slot of a column that row it changes (the column's entry in row it)
+//     is recomputed in the staged copy -- P*theta + d when x_j was set, - d
+//     when cleared (affect, itm-common.hpp:393-436), the same two operations
+//     on the same operands -- so the sums see exactly what a reload would
+//     return.  Which slot that is comes from a byte per column ("slot of the
+//     column's entry in the row that touched it last"), checked against the
+//     staged row ids;
+//   * compute_violated_constraints (itm-common.hpp:102-115) at the end of the
+//     sweep goes over the SET bits of x and their columns, not over the rows.
+//
+// LDS per instance (aa04 shape, fp64): pi 3.4 KB, x 1.8, row list and row
+// constants 8.5, slot bytes 7, descriptors 3 x 4, column lines 2 x 20, the
+// buffers of one row 10: about 85 KB.
+#pragma once
+
+#include "bxh_kernels.hpp"
+
+namespace bxh {
+
+struct NarrowParams
+{
+    const int4* desc; // [nnz][2] per CSR element: {first CSC slot of its column, real entries of
+                      //  the column, CSC slot of the element, column (bit 31: coefficient -1)},
+                      //  {cost of the column as Float bits, 0, 0}
+};
+
+struct NarrowLds
+{
+    int off_pi, off_x, off_rows, off_rowc, off_slot, off_desc, off_cols, off_val, off_key, off_id,
+      off_tab, off_rank, off_stale, off_misc, total, n2;
+    int rp;        // row positions staged (64 * NE)
+    int desc_size; // bytes of one descriptor buffer
+    int cols_size; // bytes of one column buffer (P lines, then row ids)
+    int ids_off;   // offset of the row ids inside a column buffer
+};
+
+__host__ __device__ inline NarrowLds
+narrow_lds(int m, int n, int nwords, int rmax, int fsize, int ne, int npc)
+{
+    auto al = [](int v) { return (v + 15) & ~15; };
+    NarrowLds p;
+    const int n2 = next_pow2(rmax < 2 ? 2 : rmax);
+    p.n2 = n2;
+    p.rp = 64 * ne;
+    p.desc_size = p.rp * 32;
+    p.ids_off = npc * p.rp * 16 * fsize;
+    p.cols_size = p.ids_off + npc * p.rp * 32;
+    int o = 0;
+    p.off_pi = o;
+    o = al(o + (m + 1) * fsize);
+    p.off_x = o;
+    o = al(o + nwords * 8);
+    p.off_rows = o;
+    o = al(o + m * 4);
+    p.off_rowc = o; // {first element, length | c_size << 16, bmin, bmax} of every row of the list
+    o = al(o + m * 16);
+    p.off_slot = o; // per column: slot (inside the column) of its entry in the row that wrote it last
+    o = al(o + n);
+    p.off_desc = o; // 3 descriptor buffers (rows it, it+1, it+2)
+    o = al(o + 3 * p.desc_size);
+    p.off_cols = o; // 2 column buffers (rows it, it+1); the row activities after the sweep
+    // The buffers of the sort path (and the tie filter) use the column buffer of
+    // the NEXT row: its lines are still in registers while a row is decided, and
+    // are stored there afterwards.
+    int rowbuf = al(rmax * fsize) + al(n2 * 8) + al(n2 * 4) + al(2 * n2 * 8 > 1024 ? 2 * n2 * 8 : 1024) + al(n2 * 4);
+    int cs2 = p.cols_size > rowbuf ? p.cols_size : rowbuf;
+    p.cols_size = cs2;
+    o = al(o + (2 * cs2 > (m + 1) * 4 ? 2 * cs2 : (m + 1) * 4));
+    // offsets inside a column buffer
+    {
+        int q = 0;
+        p.off_val = q;
+        q = al(q + rmax * fsize);
+        p.off_key = q;
+        q = al(q + n2 * 8);
+        p.off_id = q;
+        q = al(q + n2 * 4);
+        p.off_tab = q; // tie filter of the sort-free path (1 KB); scratch of the sorts (2 * n2 keys)
+        q = al(q + (2 * n2 * 8 > 1024 ? 2 * n2 * 8 : 1024));
+        p.off_rank = q;
+    }
+    p.off_stale = o;
+    o = al(o + (rmax + 1) * fsize);
+    p.off_misc = o;
+    o = al(o + 96 * 4);
+    p.total = o;
+    return p;
+}
+
+// One padded piece (16 CSC slots) of a column: the P values and the packed row
+// ids (16 bits each: row, bit 15 = coefficient -1; padding slots hold row m).
+template<typename Float>
+struct NarrowPiece
+{
+    Float p[16];
+    unsigned id[8];
+};
+
+template<typename Float>
+__device__ inline void
+narrow_load_piece(const Float* P, const unsigned short* ids, int q, NarrowPiece<Float>& out)
+{
+    if constexpr (sizeof(Float) == 8) {
+        const double2* src = reinterpret_cast<const double2*>(P + q);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double2 t = src[u];
+            out.p[2 * u] = t.x;
+            out.p[2 * u + 1] = t.y;
+        }
+    } else {
+        const float4* src = reinterpret_cast<const float4*>(P + q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 t = src[u];
+            out.p[4 * u] = t.x;
+            out.p[4 * u + 1] = t.y;
+            out.p[4 * u + 2] = t.z;
+            out.p[4 * u + 3] = t.w;
+        }
+    }
+    const uint4* is = reinterpret_cast<const uint4*>(ids + q);
+    const uint4 a = is[0], b = is[1];
+    out.id[0] = a.x;
+    out.id[1] = a.y;
+    out.id[2] = a.z;
+    out.id[3] = a.w;
+    out.id[4] = b.x;
+    out.id[5] = b.y;
+    out.id[6] = b.z;
+    out.id[7] = b.w;
+}
+
+// 16 bytes per lane from global memory straight into LDS (no registers): lane
+// L's bytes land at lds_dst + 16 * L.  lds_dst is wave-uniform.  Counted by
+// vmcnt like any load; the data may be read from LDS after s_waitcnt vmcnt(0).
+__device__ inline void
+narrow_dma16(const void* src, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n"
+                 "s_mov_b32 m0, %2\n"
+                 "s_nop 0\n"
+                 "global_load_lds_dwordx4 %1, off\n"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+
+// Tie filter of a row of at most 256 keys: 256 words of LDS, three bits of one
+// word per key (see filter_insert).
+__device__ inline bool
+narrow_filter_insert(unsigned* bitmap, unsigned long long key)
+{
+    unsigned x = (unsigned)(key >> 32) * 0x9E3779B1u + (unsigned)key * 0x85EBCA77u;
+    x ^= x >> 15;
+    x *= 0xC2B2AE3Du;
+    x ^= x >> 13;
+    const unsigned word = x >> 24;
+    const unsigned bits = (1u << (x & 31)) | (1u << ((x >> 5) & 31)) | (1u << ((x >> 10) & 31));
+    return (atomicOr(&bitmap[word], bits) & bits) == bits;
+}
+
+// compute_order::run / push_and_run (itm-common.hpp:682-880) around
+// compute_update_row / push_and_compute_update_row of the 01 and 101 solvers
+// (itm-solver-inequalities-01.cpp:208-296, -equalities-01.cpp:184-270,
+//  -equalities-101.cpp:208-307, -inequalities-101.cpp:250-347), one wave per
+// instance.  NE: row elements per lane (rmax <= 64 * NE), NPC: pieces of a
+// column that are staged ahead (longer columns fetch the rest on demand).
+typedef unsigned narrow_v4u __attribute__((ext_vector_type(4)));
+
+template<typename Float, bool PM1, int NE, int NPC>
+__global__ __launch_bounds__(64) void
+sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int inst = blockIdx.x;
+    if (a.active && !a.active[inst])
+        return;
+
+    constexpr int FS = (int)sizeof(Float);
+    constexpr int PB = 16 * FS;      // bytes of one piece of P
+    constexpr int CH = PB / 16;      // its 16-byte chunks (8 / 4)
+    constexpr int EPC = 16 / FS;     // values per chunk (2 / 4)
+    constexpr int CPI = 64 / CH;     // columns one load instruction covers (8 / 16)
+    constexpr int RP = 64 * NE;      // row positions
+    const NarrowLds L = narrow_lds(pb.m, pb.n, pb.nwords, pb.rmax, FS, NE, NPC);
+    Float* pi_s = (Float*)(smem + L.off_pi);
+    unsigned* x_s = (unsigned*)(smem + L.off_x);
+    int* rows_s = (int*)(smem + L.off_rows);
+    int4* rowc_s = (int4*)(smem + L.off_rowc);
+    unsigned char* slot_s = smem + L.off_slot;
+    int* act_s = (int*)(smem + L.off_cols);
+    Float* stale_s = (Float*)(smem + L.off_stale);
+    int* misc_s = (int*)(smem + L.off_misc);
+    Float* d_s = (Float*)(misc_s + MS_D);
+    // LDS addresses (the DMA destination is an address, not a pointer)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const int lane = threadIdx.x;
+    const bool maximize = pb.maximize != 0;
+    const int kind = pb.kind;
+
+    Float* P = (Float*)st.P + (size_t)inst * pb.nnzp;
+    Float* pig = (Float*)st.pi + (size_t)inst * pb.m;
+    unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
+    Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
+    const int ord = order_of(a, inst);
+    const bool use_m = ord == 3 || ord == 4;
+    const bool keep = use_m || ord == 7;
+    int* vlist = use_m ? st.mrun + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
+    int* out_list = keep ? st.slist + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
+    const Float* cost = (const Float*)pb.cost;
+    const unsigned short* ids16 = pb.col_row16;
+
+    const Float kappa = (Float)a.kappa[inst];
+    const Float delta = (Float)a.delta;
+    const Float theta = (Float)a.theta;
+    const Float obj_amp = (Float)a.obj_amp;
+    const bool push = a.is_push != 0;
+    const Float kfac = kappa / ((Float)1 - kappa);
+
+    const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
+    for (int i = lane; i < pb.m; i += 64)
+        pi_s[i] = pig[i];
+    if (lane == 0)
+        pi_s[pb.m] = (Float)0; // the row of the padding slots
+    for (int i = lane; i < 2 * pb.nwords; i += 64)
+        x_s[i] = xg[i];
+    for (int i = lane; i <= pb.rmax; i += 64)
+        stale_s[i] = staleg[i];
+    for (int i = lane; i < nrows; i += 64)
+        rows_s[i] = vlist[i];
+    for (int i = lane; i < (pb.n + 3) / 4; i += 64)
+        ((unsigned*)slot_s)[i] = 0u;
+    // push sweeps of the 01 solvers add the cost at the LOCAL id of the element
+    // (a quirk of the reference): the same per lane for every row
+    Float cost_local[NE];
+#pragma unroll
+    for (int s = 0; s < NE; ++s)
+        cost_local[s] = (!PM1 && push && lane + 64 * s < pb.n) ? cost[lane + 64 * s] : (Float)0;
+
+    MinStd rng;
+    rng.s = st.status[inst].rng; // every lane tracks the engine
+    double alg_bytes = 0.0;
+    Prof prof;
+    (void)prof;
+#ifdef BXH_PROFILE
+    for (int i = 0; i < 16; ++i)
+        prof.acc[i] = 0;
+    prof.t = wall_clock64();
+#endif
+
+    if (lane == 0)
+        misc_s[MS_PICH] = 0;
+    __syncthreads();
+    // compute_order: random_sorting shuffles the list before the sweep
+    // (itm-common.hpp:708-714 / :817-823)
+    if (ord == 2 || ord == 7) {
+        if (lane == 0) {
+            rng.shuffle(rows_s, (unsigned)nrows);
+            misc_s[MS_RNG] = (int)rng.s;
+        }
+        __syncthreads();
+        rng.s = (unsigned)misc_s[MS_RNG];
+    }
+
+    // The constants of every row of the list, in sweep order, fetched by all
+    // lanes at once (the row loop then reads them from LDS: no memory round trip
+    // per row), and the algorithmic bytes of the sweep (every row of the list is
+    // updated exactly once; the figures are whole numbers, any order adds up the same).
+    {
+        double bytes = 0.0;
+        for (int i = lane; i < nrows; i += 64) {
+            const int k = (ord == 1) ? rows_s[nrows - 1 - i] : rows_s[i];
+            const int rs = pb.row_ptr[k];
+            const int r = pb.row_ptr[k + 1] - rs;
+            const int cs = PM1 ? pb.bneg[k] : 0;
+            rowc_s[i] = make_int4(rs, r | (cs << 16), pb.bmin[k], pb.bmax[k]);
+            bytes += pb.row_bytes[k];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            bytes += __shfl_xor(bytes, o, 64);
+        alg_bytes = bytes;
+    }
+    __syncthreads();
+
+    // ---- the two stages of loads ahead of the row loop ------------------------
+    // descriptors of row `it` -> buffer it % 3: lane L brings half (L & 1) of the
+    // 32-byte descriptor of element 32 * k + (L >> 1): 1 KB, contiguous, per instruction
+    auto issue_desc = [&](int it) {
+        if (it >= nrows)
+            return;
+        const int4 c = rowc_s[it];
+        const int rs = __builtin_amdgcn_readfirstlane(c.x);
+        const int r = __builtin_amdgcn_readfirstlane(c.y & 0xffff);
+        const unsigned dst = lds0 + (unsigned)L.off_desc + (unsigned)(it % 3) * (unsigned)L.desc_size;
+        const char* src = (const char*)np.desc + ((size_t)rs * 32 + (size_t)lane * 16);
+#pragma unroll
+        for (int k = 0; k < RP / 32; ++k)
+            if (32 * k < r) { // (uniform)
+                if (32 * k + (lane >> 1) < r)
+                    narrow_dma16(src + k * 1024, __builtin_amdgcn_readfirstlane(dst + k * 1024));
+            }
+    };
+    // column lines of row `it` -> buffer it & 1, by the descriptors in buffer it % 3.
+    // P: lane L brings a 16-byte chunk of the line of column CPI * i + L / CH; which
+    // chunk is swizzled by the column so that the owner's reads (lane == column) of
+    // one chunk number spread over all banks.  Row ids: two lanes per column.
+    // (plain loads into registers, stored to LDS by land_cols() once they have
+    // arrived: the LDS-DMA form of the same loads issued four times slower)
+    constexpr int NIP = RP / CPI, NII = RP / 32;
+    narrow_v4u creg[NPC][NIP + NII];
+    auto issue_cols = [&](int it) {
+        if (it >= nrows)
+            return;
+        const int r = __builtin_amdgcn_readfirstlane(rowc_s[it].y & 0xffff);
+        const int4* dsc = (const int4*)(smem + L.off_desc + (it % 3) * L.desc_size);
+        // first every descriptor this lane needs (LDS reads, all in flight together),
+        // then the loads; lanes beyond the row read the row's first column again
+        int2 dp[NIP], di[NII];
+#pragma unroll
+        for (int i = 0; i < NIP; ++i) {
+            const int c = CPI * i + lane / CH;
+            dp[i] = *(const int2*)&dsc[(c < r ? c : 0) * 2];
+        }
+#pragma unroll
+        for (int i = 0; i < NII; ++i) {
+            const int c = 32 * i + (lane >> 1);
+            di[i] = *(const int2*)&dsc[(c < r ? c : 0) * 2];
+        }
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) {
+#pragma unroll
+            for (int i = 0; i < NIP; ++i) {
+                const int c = CPI * i + lane / CH;
+                const int u = (lane % CH) ^ (c & (CH - 1));
+                const int q = (pc == 0 || pc * 16 < dp[i].y) ? dp[i].x + pc * 16 : dp[i].x;
+                creg[pc][i] = *(const narrow_v4u*)((const char*)(P + q) + u * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NII; ++i) {
+                const int c = 32 * i + (lane >> 1);
+                const int h = (lane & 1) ^ ((c >> 2) & 1);
+                const int q = (pc == 0 || pc * 16 < di[i].y) ? di[i].x + pc * 16 : di[i].x;
+                creg[pc][NIP + i] = *(const narrow_v4u*)((const char*)(ids16 + q) + h * 16);
+            }
+        }
+    };
+    auto land_cols = [&](int it) {
+        if (it >= nrows)
+            return;
+        unsigned char* cb = smem + L.off_cols + (it & 1) * L.cols_size;
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) {
+#pragma unroll
+            for (int i = 0; i < NIP; ++i)
+                *(narrow_v4u*)(cb + pc * RP * PB + i * 1024 + lane * 16) = creg[pc][i];
+#pragma unroll
+            for (int i = 0; i < NII; ++i)
+                *(narrow_v4u*)(cb + L.ids_off + pc * RP * 32 + i * 1024 + lane * 16) = creg[pc][NIP + i];
+        }
+    };
+    auto wait_loads = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    issue_desc(0);
+    issue_desc(1);
+    wait_loads();
+    issue_cols(0);
+    wait_loads();
+    land_cols(0);
+    BXH_PSTAMP(&prof, 0);
+
+    int kprev = -1;       // the row updated just before (its P stores are not in the staged lines)
+    Float dprev = (Float)0;
+
+    for (int it = 0; it < nrows; ++it) {
+        // ---- the loads of the rows ahead (complete at this row's wait_loads) -----
+        issue_desc(it + 2);
+        issue_cols(it + 1);
+        BXH_PSTAMP(&prof, 1);
+
+        const int4 rowc = rowc_s[it];
+        const int k = __builtin_amdgcn_readfirstlane(
+          (ord == 1) ? rows_s[nrows - 1 - it] : rows_s[it]);
+        const int r = __builtin_amdgcn_readfirstlane(rowc.y & 0xffff);
+        const int row_bmin = __builtin_amdgcn_readfirstlane(rowc.z);
+        const int row_bmax = __builtin_amdgcn_readfirstlane(rowc.w);
+        const int row_csize = PM1 ? __builtin_amdgcn_readfirstlane(rowc.y >> 16) : 0;
+        const int4* dsc = (const int4*)(smem + L.off_desc + (it % 3) * L.desc_size);
+        unsigned char* cbuf = smem + L.off_cols + (it & 1) * L.cols_size;
+        // the sort path's buffers and the tie filter: in the other column buffer
+        unsigned char* rbuf = smem + L.off_cols + ((it + 1) & 1) * L.cols_size;
+        Float* val_s = (Float*)(rbuf + L.off_val);
+        unsigned long long* key_s = (unsigned long long*)(rbuf + L.off_key);
+        int* id_s = (int*)(rbuf + L.off_id);
+        unsigned* filt_s = (unsigned*)(rbuf + L.off_tab);
+        unsigned long long* key_run = (unsigned long long*)(rbuf + L.off_tab);
+        int* id_run = (int*)(key_run + L.n2);
+        int* rank_s = (int*)(rbuf + L.off_rank);
+
+        // ---- decrease_preference + compute_reduced_costs (+ push) ----------
+        struct Elem
+        {
+            int pe, jw, own; // CSC slot of the element, column | sign bit, slot inside the column
+        };
+        Elem el[NE];
+        Float v[NE], pown[NE];
+        unsigned long long key[NE];
+#pragma unroll
+        for (int s = 0; s < NE; ++s) {
+            const int idx = lane + 64 * s;
+            v[s] = (Float)0;
+            pown[s] = (Float)0;
+            key[s] = ~0ull;
+            el[s].pe = 0;
+            el[s].jw = 0;
+            el[s].own = 0;
+            if (idx < r) {
+                const int4 d0 = dsc[idx * 2];
+                const int4 d1 = dsc[idx * 2 + 1];
+                const int q0 = d0.x, len = d0.y, pe = d0.z;
+                el[s].pe = pe;
+                el[s].jw = d0.w;
+                const int j = d0.w & 0x7fffffff;
+                const bool eneg = PM1 && d0.w < 0;
+                const int own = pe - q0;
+                el[s].own = own;
+                Float cj;
+                if constexpr (FS == 8)
+                    cj = (Float)__longlong_as_double(((long long)(unsigned)d1.y << 32) | (unsigned)d1.x);
+                else
+                    cj = (Float)__int_as_float(d1.x);
+                // where element t of the column sits in the staged copy
+                auto p_at = [&](int t) -> Float* {
+                    const int pc = t >> 4, tt = t & 15;
+                    const int u = (tt / EPC) ^ (idx & (CH - 1));
+                    return (Float*)(cbuf + pc * RP * PB + idx * PB + u * 16) + (tt % EPC);
+                };
+                auto id_at = [&](int t) -> unsigned {
+                    const int pc = t >> 4, tt = t & 15;
+                    const int h = (tt >> 3) ^ ((idx >> 2) & 1);
+                    return *((const unsigned short*)(cbuf + L.ids_off + pc * RP * 32 + idx * 32 + h * 16) +
+                             (tt & 7));
+                };
+                // the slot the previous row has just stored: recomputed in the staged copy
+                {
+                    const int sp = (int)slot_s[j];
+                    if (sp < NPC * 16 && sp < len && (int)(id_at(sp) & 0x7fffu) == kprev) {
+                        const bool xbit = (x_s[j >> 5] >> (j & 31)) & 1u;
+                        Float* pp = p_at(sp);
+                        Float pv = *pp * theta;
+                        pv = pv + (xbit ? dprev : -dprev);
+                        *pp = pv;
+                    }
+                }
+                // P[e] *= theta (written back by affect)
+                Float po = 0;
+                if (own < NPC * 16) {
+                    Float* pp = p_at(own);
+                    po = *pp * theta;
+                    *pp = po;
+                }
+                Float spi = 0, sp = 0;
+                auto accumulate = [&](const NarrowPiece<Float>& pcs, int base, bool check_own) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const unsigned h = (pcs.id[t >> 1] >> ((t & 1) * 16)) & 0xffffu;
+                        const int row = (int)(h & 0x7fffu);
+                        Float pv = pcs.p[t];
+                        if (check_own && base + t == own) {
+                            pv = pv * theta;
+                            po = pv;
+                        }
+                        const Float piv = pi_s[row];
+                        if (PM1) {
+                            const bool neg = (h & 0x8000u) != 0;
+                            spi += neg ? -piv : piv;
+                            sp += neg ? -pv : pv;
+                        } else {
+                            spi += piv;
+                            sp += pv;
+                        }
+                    }
+                };
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc)
+                    if (pc == 0 || pc * 16 < len) {
+                        NarrowPiece<Float> pcs;
+                        const unsigned char* pl = cbuf + pc * RP * PB + idx * PB;
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            const uint4 w = *(const uint4*)(pl + ((u ^ (idx & (CH - 1))) * 16));
+                            if constexpr (FS == 8) {
+                                pcs.p[2 * u] = __longlong_as_double(((long long)w.y << 32) | w.x);
+                                pcs.p[2 * u + 1] = __longlong_as_double(((long long)w.w << 32) | w.z);
+                            } else {
+                                pcs.p[4 * u] = __uint_as_float(w.x);
+                                pcs.p[4 * u + 1] = __uint_as_float(w.y);
+                                pcs.p[4 * u + 2] = __uint_as_float(w.z);
+                                pcs.p[4 * u + 3] = __uint_as_float(w.w);
+                            }
+                        }
+                        const unsigned char* il = cbuf + L.ids_off + pc * RP * 32 + idx * 32;
+                        const uint4 ia = *(const uint4*)(il + (((idx >> 2) & 1) * 16));
+                        const uint4 ib = *(const uint4*)(il + ((((idx >> 2) & 1) ^ 1) * 16));
+                        pcs.id[0] = ia.x;
+                        pcs.id[1] = ia.y;
+                        pcs.id[2] = ia.z;
+                        pcs.id[3] = ia.w;
+                        pcs.id[4] = ib.x;
+                        pcs.id[5] = ib.y;
+                        pcs.id[6] = ib.z;
+                        pcs.id[7] = ib.w;
+                        accumulate(pcs, pc * 16, false);
+                    }
+                for (int b = NPC * 16; b < len; b += 16) { // the rest of a long column: fetched now
+                    NarrowPiece<Float> extra;
+                    narrow_load_piece<Float>(P, ids16, q0 + b, extra);
+                    accumulate(extra, b, true);
+                }
+                Float vv = cj - spi - sp;
+                if (eneg)
+                    vv = -vv;
+                if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
+                    vv += obj_amp * (PM1 ? cj : cost_local[s]);
+                v[s] = vv;
+                pown[s] = po;
+                key[s] = order_key<Float>(vv, maximize);
+            }
+        }
+
+        BXH_PSTAMP(&prof, 2);
+        // ---- selection without sorting (see sweep_kernel_v2): class counts,
+        // the extreme keys and the keys next to the class borders ------------
+        bool fast = false;
+        int f_mode = 0, f_nN = 0, f_nZ = 0;
+        unsigned long long f_thr = 0ull;
+        Float f_d = 0, f_newpi = 0;
+        bool f_pich = false;
+        if (r >= 2) {
+            const unsigned long long K0 = order_key<Float>((Float)0, maximize);
+            reinterpret_cast<uint4*>(filt_s)[lane] = make_uint4(0u, 0u, 0u, 0u); // 256 words
+            unsigned long long A = ~0ull, A2 = ~0ull, B = ~0ull, C = ~0ull, D = ~0ull;
+            int cN = 0, cZ = 0;
+            bool flagged[NE];
+#pragma unroll
+            for (int s = 0; s < NE; ++s) {
+                const bool have = lane + 64 * s < r;
+                const unsigned long long kk = key[s];
+                flagged[s] = have && narrow_filter_insert(filt_s, kk);
+                const bool isN = have && kk < K0, isZ = have && kk == K0, isS = have && kk > K0;
+                cN += __popcll(__ballot(isN));
+                cZ += __popcll(__ballot(isZ));
+                if (kk < A) {
+                    A2 = A;
+                    A = kk;
+                } else
+                    A2 = umin64(A2, kk);
+                B = umin64(B, have ? ~kk : ~0ull);
+                C = umin64(C, isN ? ~kk : ~0ull);
+                D = umin64(D, isS ? kk : ~0ull);
+            }
+            // a flagged key MAY equal an earlier one: looked up in the whole row (rare)
+            bool anytie = false;
+#pragma unroll
+            for (int s = 0; s < NE; ++s) {
+                unsigned long long pending = __ballot(flagged[s]);
+                while (pending && !anytie) {
+                    const int src = __ffsll((long long)pending) - 1;
+                    pending &= pending - 1;
+                    const unsigned long long fk =
+                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key[s] >> 32), src) << 32) |
+                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key[s], src);
+                    int same = 0;
+#pragma unroll
+                    for (int s2 = 0; s2 < NE; ++s2)
+                        same += __popcll(__ballot(lane + 64 * s2 < r && key[s2] == fk));
+                    if (same >= 2)
+                        anytie = true;
+                }
+            }
+            const unsigned long long ownA = A;
+            wave_umin64x4(A, B, C, D);
+            unsigned long long E = ownA == A ? A2 : ownA;
+            E = wave_umin64(E);
+            const unsigned long long g1 = A, gx = ~B, gxN = ~C, gnS = D;
+            const int nN = cN, nZ = cZ;
+            bool ok = !anytie;
+            const unsigned saved_rng = rng.s;
+            int sel = 0;
+            unsigned long long k_sel = 0ull, k_sel1 = 0ull;
+            if (ok) {
+                auto stop = [&](Float sv) -> bool { // itm-common.hpp:150-163
+                    if (sv == 0)
+                        return rng.coin();
+                    return maximize ? sv < 0 : sv > 0;
+                };
+                const int c_size = row_csize;
+                int bkmin = row_bmin, bkmax = row_bmax;
+                if (kind == 0 || kind == 2 || bkmin == bkmax) {
+                    sel = min(bkmin + c_size, r) - 1;
+                } else {
+                    if (kind == 1) {
+                        bkmin = min(bkmin, r);
+                        bkmax = min(bkmax, r);
+                    } else {
+                        bkmin += c_size;
+                        bkmax = min(bkmax + c_size, r);
+                    }
+                    sel = bkmax - 1;
+                    int cur = bkmin;
+                    if (cur <= bkmax) {
+                        bool stopped = false;
+                        if (cur < nN)
+                            cur = nN; // N entries never stop the scan
+                        if (cur <= bkmax && cur < nN + nZ) { // the zero entry
+                            if (rng.coin())
+                                stopped = true;
+                            else
+                                ++cur;
+                        }
+                        if (!stopped && cur <= bkmax) {
+                            if (cur < r)
+                                stopped = true; // first S entry
+                            else
+                                stopped = stop(stale_s[r]); // R[r_size] (stale)
+                        }
+                        if (stopped)
+                            sel = cur - 1;
+                    }
+                }
+                auto key_at = [&](int rank, bool& good) -> unsigned long long {
+                    if (rank == 0)
+                        return g1;
+                    if (rank == 1)
+                        return E;
+                    if (rank == r - 1)
+                        return gx;
+                    if (nN > 0 && rank == nN - 1)
+                        return gxN;
+                    if (rank == nN)
+                        return nZ ? K0 : gnS;
+                    if (nZ && rank == nN + nZ)
+                        return gnS;
+                    good = false;
+                    return 0ull;
+                };
+                if (sel < 0) {
+                    k_sel = key_at(0, ok);
+                } else if (sel + 1 >= r) {
+                    k_sel = key_at(r - 1, ok);
+                } else {
+                    k_sel = key_at(sel, ok);
+                    k_sel1 = key_at(sel + 1, ok);
+                }
+            }
+            if (!ok) {
+                rng.s = saved_rng; // the sort path redoes the scan
+            } else {
+                const Float one = 1, two = 2;
+                const Float middle = (two + one) / two;
+                Float d = delta;
+                const Float v_sel = key_value<Float>(k_sel, maximize);
+                if (sel < 0) {
+                    d += kfac * (v_sel / two);
+                    f_mode = 0;
+                } else if (sel + 1 >= r) {
+                    d += kfac * (v_sel * middle);
+                    f_mode = 1;
+                } else {
+                    const Float v_sel1 = key_value<Float>(k_sel1, maximize);
+                    const Float old_pi = pi_s[k];
+                    const Float new_pi = old_pi + ((v_sel + v_sel1) / two);
+                    d += kfac * (v_sel1 - v_sel);
+                    f_mode = 2;
+                    f_thr = k_sel;
+                    f_newpi = new_pi;
+                    f_pich = signbit(old_pi) != signbit(new_pi);
+                }
+                f_d = d;
+                f_nN = nN;
+                f_nZ = nZ;
+                fast = true;
+            }
+        }
+
+        BXH_PSTAMP(&prof, 3);
+        // the columns read ahead must have landed before this row's stores to
+        // the same lines are issued
+        wait_loads();
+        BXH_PSTAMP(&prof, 4);
+
+        if (fast) {
+            const int mode = f_mode;
+            const Float d = f_d;
+            if (lane == 0) {
+                if (mode == 2) {
+                    pi_s[k] = f_newpi;
+                    if (f_pich)
+                        misc_s[MS_PICH] = 1;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NE; ++s) {
+                const int idx = lane + 64 * s;
+                if (idx < r) {
+                    const int j = el[s].jw & 0x7fffffff;
+                    const int pe = el[s].pe;
+                    bool up = mode == 1 || (mode == 2 && key[s] <= f_thr);
+                    if (PM1 && el[s].jw < 0)
+                        up = !up;
+                    const Float p = pown[s]; // P[pe] * theta
+                    if (up)
+                        atomicOr(&x_s[j >> 5], 1u << (j & 31));
+                    else
+                        atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
+                    P[pe] = up ? p + d : p - d;
+                    slot_s[j] = (unsigned char)el[s].own;
+                    // R[pos].value after the sort only matters through
+                    // stop_iterating: keep its class (N / zero / S)
+                    const Float repN = maximize ? (Float)1 : (Float)-1;
+                    stale_s[idx] = idx < f_nN ? repN : (idx < f_nN + f_nZ ? (Float)0 : -repN);
+                }
+            }
+            dprev = d;
+            BXH_PSTAMP(&prof, 5);
+        } else {
+            // ---- calculator_sort: sort, then shuffle every run of equal values
+#pragma unroll
+            for (int s = 0; s < NE; ++s)
+                if (lane + 64 * s < r)
+                    val_s[lane + 64 * s] = v[s];
+            if (lane == 0)
+                misc_s[MS_TIE] = 0;
+            __syncthreads();
+            const int n2 = next_pow2(r < 2 ? 2 : r);
+            if (r <= 128) {
+                if (r > 1) {
+                    run_merge_sort<Float>(val_s, r, maximize, key_run, id_run, key_s, id_s, &prof);
+                } else {
+                    if (lane == 0) {
+                        key_s[0] = order_key<Float>(val_s[0], maximize);
+                        id_s[0] = 0;
+                    }
+                    __syncthreads();
+                }
+            } else {
+                for (int i = lane; i < n2; i += 64) {
+                    key_s[i] = i < r ? order_key<Float>(val_s[i], maximize) : ~0ull;
+                    id_s[i] = i;
+                }
+                __syncthreads();
+                bitonic_sort(key_s, id_s, n2);
+            }
+            for (int i = lane; i + 1 < r; i += 64)
+                if (key_s[i] == key_s[i + 1])
+                    misc_s[MS_TIE] = 1;
+            __syncthreads();
+            bool shuffled = false;
+            if (misc_s[MS_TIE] && r <= 128) {
+                unsigned stt = rng.s;
+                shuffled = parallel_tie_shuffle(key_s, id_s, r, &stt, pb.lcg_pow, (int*)key_run,
+                                                (int*)key_run + L.n2, id_run, misc_s + MS_WAVES);
+                if (shuffled)
+                    rng.s = stt;
+            }
+            if (lane == 0) {
+                if (misc_s[MS_TIE] && !shuffled) {
+                    int b0 = 0;
+                    for (int i = 1; i <= r; ++i) {
+                        if (i == r || key_s[i] != key_s[b0]) {
+                            rng.shuffle(id_s + b0, (unsigned)(i - b0));
+                            b0 = i;
+                        }
+                    }
+                }
+                auto Rv = [&](int i) -> Float { // R[i].value, R[r] is stale
+                    return i < r ? val_s[id_s[i]] : stale_s[i];
+                };
+                auto stop = [&](Float sv) -> bool {
+                    if (sv == 0)
+                        return rng.coin();
+                    return maximize ? sv < 0 : sv > 0;
+                };
+                const int c_size = row_csize;
+                int bkmin = row_bmin, bkmax = row_bmax;
+                int sel;
+                if (kind == 0 || kind == 2 || bkmin == bkmax) {
+                    sel = min(bkmin + c_size, r) - 1;
+                } else {
+                    if (kind == 1) {
+                        bkmin = min(bkmin, r);
+                        bkmax = min(bkmax, r);
+                    } else {
+                        bkmin += c_size;
+                        bkmax = min(bkmax + c_size, r);
+                    }
+                    sel = bkmax - 1;
+                    for (int i = bkmin; i <= bkmax; ++i)
+                        if (stop(Rv(i))) {
+                            sel = i - 1;
+                            break;
+                        }
+                }
+                const Float one = 1, two = 2;
+                const Float middle = (two + one) / two;
+                Float d = delta;
+                if (sel < 0) {
+                    d += kfac * (Rv(0) / two);
+                } else if (sel + 1 >= r) {
+                    d += kfac * (Rv(sel) * middle);
+                } else {
+                    const Float old_pi = pi_s[k];
+                    const Float new_pi = old_pi + ((Rv(sel) + Rv(sel + 1)) / two);
+                    pi_s[k] = new_pi;
+                    d += kfac * (Rv(sel + 1) - Rv(sel));
+                    if (signbit(old_pi) != signbit(new_pi))
+                        misc_s[MS_PICH] = 1;
+                }
+                misc_s[MS_SEL] = sel;
+                *d_s = d;
+                misc_s[MS_RNG] = (int)rng.s;
+            }
+            __syncthreads();
+            rng.s = (unsigned)misc_s[MS_RNG];
+            const int sel = misc_s[MS_SEL];
+            const Float d = *d_s;
+            for (int i = lane; i < r; i += 64)
+                rank_s[id_s[i]] = i;
+            __syncthreads();
+            for (int i = lane; i < r; i += 64)
+                stale_s[i] = val_s[id_s[i]]; // R[i].value after the sort
+#pragma unroll
+            for (int s = 0; s < NE; ++s) {
+                const int idx = lane + 64 * s;
+                if (idx < r) {
+                    const int j = el[s].jw & 0x7fffffff;
+                    const int pe = el[s].pe;
+                    bool up = rank_s[idx] <= sel; // sel < 0: none; sel + 1 >= r: all
+                    if (PM1 && el[s].jw < 0)
+                        up = !up;
+                    const Float p = pown[s];
+                    if (up)
+                        atomicOr(&x_s[j >> 5], 1u << (j & 31));
+                    else
+                        atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
+                    P[pe] = up ? p + d : p - d;
+                    slot_s[j] = (unsigned char)el[s].own;
+                }
+            }
+            __syncthreads();
+            dprev = d;
+            BXH_PSTAMP(&prof, 6);
+        }
+        kprev = k;
+        land_cols(it + 1); // (the sort path's buffers, in the same place, are done with)
+
+        BXH_PSTAMP(&prof, 7);
+    }
+
+    // ---- write back, then compute_violated_constraints ---------------------
+    __syncthreads();
+    for (int i = lane; i < pb.m; i += 64)
+        pig[i] = pi_s[i];
+    for (int i = lane; i < 2 * pb.nwords; i += 64)
+        xg[i] = x_s[i];
+    for (int i = lane; i <= pb.rmax; i += 64)
+        staleg[i] = stale_s[i];
+    if (ord == 7) // pi_sign_change keeps the shuffled R
+        for (int i = lane; i < nrows; i += 64)
+            vlist[i] = rows_s[i];
+
+    // row activities from the set bits of x: every lane takes words of x, four
+    // columns at a time (their descriptor loads, then their row ids, together)
+    for (int i = lane; i <= pb.m; i += 64)
+        act_s[i] = 0;
+    __syncthreads();
+    for (int w = lane; w < 2 * pb.nwords; w += 64) {
+        unsigned word = x_s[w];
+        while (word) {
+            int jj[4], q0[4], ln[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (word) {
+                    jj[u] = w * 32 + (__ffs((int)word) - 1);
+                    word &= word - 1;
+                } else
+                    jj[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                q0[u] = jj[u] >= 0 ? pb.col_start[jj[u]] : 0;
+                ln[u] = jj[u] >= 0 ? pb.col_len[jj[u]] : 0;
+            }
+            uint4 ia[4], ib[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ln[u] > 0) {
+                    const uint4* is = reinterpret_cast<const uint4*>(ids16 + q0[u]);
+                    ia[u] = is[0];
+                    ib[u] = is[1];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ln[u] > 0) {
+                    const unsigned wd[8] = { ia[u].x, ia[u].y, ia[u].z, ia[u].w,
+                                             ib[u].x, ib[u].y, ib[u].z, ib[u].w };
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const unsigned h = (wd[t >> 1] >> ((t & 1) * 16)) & 0xffffu;
+                        if (t < ln[u])
+                            atomicAdd(&act_s[h & 0x7fffu], (h & 0x8000u) ? -1 : 1);
+                    }
+                    for (int t = 16; t < ln[u]; ++t) {
+                        const unsigned h = ids16[q0[u] + t];
+                        atomicAdd(&act_s[h & 0x7fffu], (h & 0x8000u) ? -1 : 1);
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int c = 0; c < pb.m; c += 64) {
+        const int k = c + lane;
+        bool f = false;
+        if (k < pb.m) {
+            const int av = act_s[k];
+            f = !(pb.bmin[k] <= av && av <= pb.bmax[k]);
+        }
+        const unsigned long long mask = __ballot(f);
+        if (f)
+            out_list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+        cnt += __popcll(mask);
+    }
+
+    BXH_PSTAMP(&prof, 8);
+#ifdef BXH_PROFILE
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i)
+            st.prof[(size_t)inst * 32 + i] += prof.acc[i];
+#endif
+    if (lane == 0) {
+        if (!keep)
+            st.vcount[inst] = cnt;
+        DevStatus s = st.status[inst];
+        s.remaining = cnt;
+        s.pi_changed = misc_s[MS_PICH];
+        s.rng = rng.s;
+        s.rows_in_sweep = (unsigned)nrows;
+        s.row_updates += (unsigned long long)nrows;
+        s.alg_bytes += alg_bytes;
+        st.status[inst] = s;
+    }
+}
+
+} // namespace bxh
