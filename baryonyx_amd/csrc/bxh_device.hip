@@ -88,7 +88,7 @@ struct bxh_handle_s
     int sw_chain = 0, sw_prod = 0; // v2: staging waves of the chain / a producer
     int romax = 0;             // longest per-owner part of a row
     int wide_g = 0;            // wide kernel (version 4): workgroups per instance
-    int narrow_ne = 0, narrow_npc = 0; // narrow kernel (version 5): elements per lane, prefetched pieces
+    int narrow_w = 0, narrow_rpq = 0; // narrow kernel (version 5): waves per instance, staged row positions / 64
     DevBuf<int4> ndesc;        // narrow kernel: per CSR element descriptors
     bxh::NarrowParams npar{};
     bool device_built = false; // bxh_create_device: no host copy of the matrix exists
@@ -310,26 +310,34 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
     } else if (h->version == 3) {
         BXH_LAUNCH((bxh::sweep_kernel_z<Float>));
     } else if (h->version == 5) {
-#define BXH_NARROW(PM, NE, NPC)                                                \
-    hipLaunchKernelGGL((bxh::sweep_kernel_narrow<Float, PM, NE, NPC>), dim3(h->batch), dim3(64), \
+#define BXH_NARROW(PM, WW, RQ)                                                 \
+    hipLaunchKernelGGL((bxh::sweep_kernel_narrow<Float, PM, WW, RQ>), dim3(h->batch), dim3(64 * WW), \
                        h->lds_bytes, h->stream, h->dp, h->ds, a, h->npar)
+#define BXH_NARROW_W(PM, WW)                                                   \
+    do {                                                                       \
+        if (h->narrow_rpq == 1)                                                \
+            BXH_NARROW(PM, WW, 1);                                             \
+        else if (h->narrow_rpq == 2)                                           \
+            BXH_NARROW(PM, WW, 2);                                             \
+        else if (h->narrow_rpq == 3)                                           \
+            BXH_NARROW(PM, WW, 3);                                             \
+        else                                                                   \
+            BXH_NARROW(PM, WW, 4);                                             \
+    } while (0)
 #define BXH_NARROW_PM(PM)                                                      \
     do {                                                                       \
-        if (h->narrow_ne == 1 && h->narrow_npc == 1)                           \
+        if (h->narrow_w == 4)                                                  \
+            BXH_NARROW_W(PM, 4);                                               \
+        else if (h->narrow_rpq == 1)                                           \
             BXH_NARROW(PM, 1, 1);                                              \
-        else if (h->narrow_ne == 1)                                            \
-            BXH_NARROW(PM, 1, 2);                                              \
-        else if (h->narrow_ne == 2 && h->narrow_npc == 1)                      \
-            BXH_NARROW(PM, 2, 1);                                              \
-        else if (h->narrow_ne == 2)                                            \
-            BXH_NARROW(PM, 2, 2);                                              \
         else                                                                   \
-            BXH_NARROW(PM, 4, 1);                                              \
+            BXH_NARROW(PM, 1, 2);                                              \
     } while (0)
         if (pm1)
             BXH_NARROW_PM(true);
         else
             BXH_NARROW_PM(false);
+#undef BXH_NARROW_W
 #undef BXH_NARROW_PM
 #undef BXH_NARROW
     } else if (h->version == 4) {
@@ -486,11 +494,10 @@ bxh_create(const bxh_problem* pb,
         const char* en = std::getenv("BXH_NARROW");
         const bool asked = en && en[0] == '1';
         const bool off = (en && en[0] == '0') || std::getenv("BXH_GROUPS") || (force_v1 && force_v1[0] == '1');
-        const int ne = rmax <= 64 ? 1 : (rmax <= 128 ? 2 : 4);
-        const int npc = (cmax <= 16 || ne == 4) ? 1 : 2;
-        const int nl = bxh::narrow_lds(m, n, h->nwords, rmax, float_type == BXH_FLOAT ? 4 : 8, ne, npc).total;
+        const int rpq = (rmax + 63) / 64;
+        const int nl = bxh::narrow_lds(m, n, h->nwords, rmax, float_type == BXH_FLOAT ? 4 : 8, rpq).total;
         narrow = !wide_g && !zsolver && pb->n_quad == 0 && rmax <= 256 && cmax <= 128 && m < 32767 &&
-                 nl <= 160 * 1024 && !off && (asked || (cmax <= 32 && rmax <= 64));
+                 nl <= 160 * 1024 && !off && (asked || cmax <= 32);
     }
     const bool v2_ok = !narrow && !wide_g && !zsolver && cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
     int groups = 1;
@@ -933,10 +940,15 @@ bxh_create(const bxh_problem* pb,
     if (narrow) {
         h->version = 5;
         h->threads = 64;
-        h->narrow_ne = rmax <= 64 ? 1 : (rmax <= 128 ? 2 : 4);
-        h->narrow_npc = (cmax <= 16 || h->narrow_ne == 4) ? 1 : 2;
+        h->narrow_rpq = (rmax + 63) / 64;
+        // four waves (one per SIMD of the CU) share a row of more than 64 elements;
+        // BXH_NARROW_W=1 / 4 decides otherwise
+        h->narrow_w = rmax > 64 ? 4 : 1;
+        if (const char* ew = std::getenv("BXH_NARROW_W"))
+            h->narrow_w = (std::atoi(ew) == 4 || h->narrow_rpq > 2) ? 4 : 1; // (one wave: rows of up to 128)
+        h->threads = 64 * h->narrow_w;
         h->lds_bytes = static_cast<size_t>(
-          bxh::narrow_lds(m, n, h->nwords, rmax, static_cast<int>(h->fsize), h->narrow_ne, h->narrow_npc).total);
+          bxh::narrow_lds(m, n, h->nwords, rmax, static_cast<int>(h->fsize), h->narrow_rpq).total);
     }
     if (std::getenv("BXH_DEBUG"))
         std::fprintf(stderr, "bxh: kernel v%d threads=%d lds=%zu np=%d groups=%d pipe=%d (chain %d, producer %d staging waves, lookahead %d)\n",
@@ -1183,18 +1195,22 @@ bxh_create(const bxh_problem* pb,
 
     if (narrow && h->lds_bytes > 64 * 1024) {
         const int nl = static_cast<int>(h->lds_bytes);
+#define BXH_SET_NARROW1(F, PM, WW, RQ)                                         \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, WW, RQ>), hipFuncAttributeMaxDynamicSharedMemorySize, nl))
 #define BXH_SET_NARROW(F, PM)                                                  \
     do {                                                                       \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, nl)); \
+        BXH_SET_NARROW1(F, PM, 1, 1);                                          \
+        BXH_SET_NARROW1(F, PM, 1, 2);                                          \
+        BXH_SET_NARROW1(F, PM, 4, 1);                                          \
+        BXH_SET_NARROW1(F, PM, 4, 2);                                          \
+        BXH_SET_NARROW1(F, PM, 4, 3);                                          \
+        BXH_SET_NARROW1(F, PM, 4, 4);                                          \
     } while (0)
         BXH_SET_NARROW(float, false);
         BXH_SET_NARROW(float, true);
         BXH_SET_NARROW(double, false);
         BXH_SET_NARROW(double, true);
+#undef BXH_SET_NARROW1
 #undef BXH_SET_NARROW
     }
     // the kernels may ask for more than the 64 KiB default dynamic LDS

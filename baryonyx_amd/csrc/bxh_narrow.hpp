@@ -50,24 +50,25 @@ struct NarrowParams
 struct NarrowLds
 {
     int off_pi, off_x, off_rows, off_rowc, off_slot, off_desc, off_cols, off_val, off_key, off_id,
-      off_tab, off_rank, off_stale, off_misc, total, n2;
-    int rp;        // row positions staged (64 * NE)
+      off_tab, off_rank, off_stale, off_misc, off_part, total, n2;
+    int rp;        // row positions staged (64 * RPQ)
     int desc_size; // bytes of one descriptor buffer
     int cols_size; // bytes of one column buffer (P lines, then row ids)
     int ids_off;   // offset of the row ids inside a column buffer
 };
 
+// rpq: staged row positions / 64 (rmax <= 64 * rpq)
 __host__ __device__ inline NarrowLds
-narrow_lds(int m, int n, int nwords, int rmax, int fsize, int ne, int npc)
+narrow_lds(int m, int n, int nwords, int rmax, int fsize, int rpq)
 {
     auto al = [](int v) { return (v + 15) & ~15; };
     NarrowLds p;
     const int n2 = next_pow2(rmax < 2 ? 2 : rmax);
     p.n2 = n2;
-    p.rp = 64 * ne;
+    p.rp = 64 * rpq;
     p.desc_size = p.rp * 32;
-    p.ids_off = npc * p.rp * 16 * fsize;
-    p.cols_size = p.ids_off + npc * p.rp * 32;
+    p.ids_off = p.rp * 16 * fsize;
+    p.cols_size = p.ids_off + p.rp * 32;
     int o = 0;
     p.off_pi = o;
     o = al(o + (m + 1) * fsize);
@@ -106,6 +107,8 @@ narrow_lds(int m, int n, int nwords, int rmax, int fsize, int ne, int npc)
     o = al(o + (rmax + 1) * fsize);
     p.off_misc = o;
     o = al(o + 96 * 4);
+    p.off_part = o; // 2 x 16 u64: partial reductions of the waves, one set per row parity
+    o = al(o + 2 * 16 * 8);
     p.total = o;
     return p;
 }
@@ -193,8 +196,16 @@ narrow_filter_insert(unsigned* bitmap, unsigned long long key)
 // column that are staged ahead (longer columns fetch the rest on demand).
 typedef unsigned narrow_v4u __attribute__((ext_vector_type(4)));
 
-template<typename Float, bool PM1, int NE, int NPC>
-__global__ __launch_bounds__(64) void
+// compute_order::run / push_and_run (itm-common.hpp:682-880) around
+// compute_update_row / push_and_compute_update_row of the 01 and 101 solvers
+// (itm-solver-inequalities-01.cpp:208-296, -equalities-01.cpp:184-270,
+//  -equalities-101.cpp:208-307, -inequalities-101.cpp:250-347).  W waves per
+// instance (1: no barrier does anything; 4: one wave per SIMD of the CU, two
+// barriers per row), RPQ * 64 staged row positions (rmax <= 64 * RPQ).  The
+// first 16-entry piece of every column is staged ahead; longer columns fetch
+// the rest on demand.
+template<typename Float, bool PM1, int W, int RPQ>
+__global__ __launch_bounds__(64 * W) void
 sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -202,13 +213,17 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
     if (a.active && !a.active[inst])
         return;
 
+    constexpr int T = 64 * W;
     constexpr int FS = (int)sizeof(Float);
     constexpr int PB = 16 * FS;      // bytes of one piece of P
     constexpr int CH = PB / 16;      // its 16-byte chunks (8 / 4)
     constexpr int EPC = 16 / FS;     // values per chunk (2 / 4)
     constexpr int CPI = 64 / CH;     // columns one load instruction covers (8 / 16)
-    constexpr int RP = 64 * NE;      // row positions
-    const NarrowLds L = narrow_lds(pb.m, pb.n, pb.nwords, pb.rmax, FS, NE, NPC);
+    constexpr int RP = 64 * RPQ;     // row positions
+    constexpr int NE = (RP + T - 1) / T; // row elements per thread
+    constexpr int NIP = RP / CPI, NII = RP / 32, NID = RP / 32; // load instructions of a row
+    constexpr int NIPW = (NIP + W - 1) / W, NIIW = (NII + W - 1) / W; // ... of one wave
+    const NarrowLds L = narrow_lds(pb.m, pb.n, pb.nwords, pb.rmax, FS, RPQ);
     Float* pi_s = (Float*)(smem + L.off_pi);
     unsigned* x_s = (unsigned*)(smem + L.off_x);
     int* rows_s = (int*)(smem + L.off_rows);
@@ -218,10 +233,14 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
     Float* stale_s = (Float*)(smem + L.off_stale);
     int* misc_s = (int*)(smem + L.off_misc);
     Float* d_s = (Float*)(misc_s + MS_D);
+    unsigned long long* part_all = (unsigned long long*)(smem + L.off_part);
     // LDS addresses (the DMA destination is an address, not a pointer)
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // (the dynamic segment starts where the static LDS of the kernel, none here, ends)
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_groupstaticsize();
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool maximize = pb.maximize != 0;
     const int kind = pb.kind;
 
@@ -245,28 +264,27 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
     const Float kfac = kappa / ((Float)1 - kappa);
 
     const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
-    for (int i = lane; i < pb.m; i += 64)
+    for (int i = tid; i < pb.m; i += T)
         pi_s[i] = pig[i];
-    if (lane == 0)
+    if (tid == 0)
         pi_s[pb.m] = (Float)0; // the row of the padding slots
-    for (int i = lane; i < 2 * pb.nwords; i += 64)
+    for (int i = tid; i < 2 * pb.nwords; i += T)
         x_s[i] = xg[i];
-    for (int i = lane; i <= pb.rmax; i += 64)
+    for (int i = tid; i <= pb.rmax; i += T)
         stale_s[i] = staleg[i];
-    for (int i = lane; i < nrows; i += 64)
+    for (int i = tid; i < nrows; i += T)
         rows_s[i] = vlist[i];
-    for (int i = lane; i < (pb.n + 3) / 4; i += 64)
+    for (int i = tid; i < (pb.n + 3) / 4; i += T)
         ((unsigned*)slot_s)[i] = 0u;
     // push sweeps of the 01 solvers add the cost at the LOCAL id of the element
-    // (a quirk of the reference): the same per lane for every row
+    // (a quirk of the reference): the same per thread for every row
     Float cost_local[NE];
 #pragma unroll
     for (int s = 0; s < NE; ++s)
-        cost_local[s] = (!PM1 && push && lane + 64 * s < pb.n) ? cost[lane + 64 * s] : (Float)0;
+        cost_local[s] = (!PM1 && push && tid + T * s < pb.n) ? cost[tid + T * s] : (Float)0;
 
     MinStd rng;
-    rng.s = st.status[inst].rng; // every lane tracks the engine
-    double alg_bytes = 0.0;
+    rng.s = st.status[inst].rng; // every thread tracks the engine
     Prof prof;
     (void)prof;
 #ifdef BXH_PROFILE
@@ -275,13 +293,24 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
     prof.t = wall_clock64();
 #endif
 
-    if (lane == 0)
+    auto part_reset = [&](unsigned long long* ps) { // thread 0
+        ps[8] = 0ull;   // largest key
+        ps[9] = 0ull;   // largest N key
+        ps[10] = ~0ull; // smallest S key
+        ps[11] = 0ull;  // counts: N in the high half, Z in the low half
+        ps[12] = 0ull;  // tie flag
+        ps[13] = ~0ull; // smallest key
+    };
+    if (tid == 0) {
         misc_s[MS_PICH] = 0;
+        part_reset(part_all);
+        part_reset(part_all + 16);
+    }
     __syncthreads();
     // compute_order: random_sorting shuffles the list before the sweep
     // (itm-common.hpp:708-714 / :817-823)
     if (ord == 2 || ord == 7) {
-        if (lane == 0) {
+        if (tid == 0) {
             rng.shuffle(rows_s, (unsigned)nrows);
             misc_s[MS_RNG] = (int)rng.s;
         }
@@ -290,12 +319,13 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
     }
 
     // The constants of every row of the list, in sweep order, fetched by all
-    // lanes at once (the row loop then reads them from LDS: no memory round trip
+    // threads at once (the row loop then reads them from LDS: no memory round trip
     // per row), and the algorithmic bytes of the sweep (every row of the list is
     // updated exactly once; the figures are whole numbers, any order adds up the same).
+    double alg_bytes = 0.0; // thread 0
     {
         double bytes = 0.0;
-        for (int i = lane; i < nrows; i += 64) {
+        for (int i = tid; i < nrows; i += T) {
             const int k = (ord == 1) ? rows_s[nrows - 1 - i] : rows_s[i];
             const int rs = pb.row_ptr[k];
             const int r = pb.row_ptr[k + 1] - rs;
@@ -306,13 +336,18 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
             bytes += __shfl_xor(bytes, o, 64);
-        alg_bytes = bytes;
+        if (lane == 0)
+            ((double*)(misc_s + MS_WAVES))[wave] = bytes;
+        __syncthreads();
+        for (int w = 0; w < W; ++w)
+            alg_bytes += ((double*)(misc_s + MS_WAVES))[w];
     }
     __syncthreads();
 
     // ---- the two stages of loads ahead of the row loop ------------------------
     // descriptors of row `it` -> buffer it % 3: lane L brings half (L & 1) of the
-    // 32-byte descriptor of element 32 * k + (L >> 1): 1 KB, contiguous, per instruction
+    // 32-byte descriptor of element 32 * k + (L >> 1): 1 KB, contiguous, per
+    // instruction (LDS-DMA: no registers); instruction k is wave k % W's
     auto issue_desc = [&](int it) {
         if (it >= nrows)
             return;
@@ -322,54 +357,49 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
         const unsigned dst = lds0 + (unsigned)L.off_desc + (unsigned)(it % 3) * (unsigned)L.desc_size;
         const char* src = (const char*)np.desc + ((size_t)rs * 32 + (size_t)lane * 16);
 #pragma unroll
-        for (int k = 0; k < RP / 32; ++k)
-            if (32 * k < r) { // (uniform)
+        for (int kk = 0; kk < (NID + W - 1) / W; ++kk) {
+            const int k = wave + W * kk;
+            if (32 * k < r) { // (wave-uniform)
                 if (32 * k + (lane >> 1) < r)
                     narrow_dma16(src + k * 1024, __builtin_amdgcn_readfirstlane(dst + k * 1024));
             }
+        }
     };
-    // column lines of row `it` -> buffer it & 1, by the descriptors in buffer it % 3.
+    // Column lines of row `it`, by the descriptors in buffer it % 3, into
+    // registers; land_cols() stores them to buffer it & 1 once they have arrived.
     // P: lane L brings a 16-byte chunk of the line of column CPI * i + L / CH; which
-    // chunk is swizzled by the column so that the owner's reads (lane == column) of
-    // one chunk number spread over all banks.  Row ids: two lanes per column.
-    // (plain loads into registers, stored to LDS by land_cols() once they have
-    // arrived: the LDS-DMA form of the same loads issued four times slower)
-    constexpr int NIP = RP / CPI, NII = RP / 32;
-    narrow_v4u creg[NPC][NIP + NII];
+    // chunk is swizzled by the column so that the owner's reads (thread == column)
+    // of one chunk number spread over all banks.  Row ids: two lanes per column.
+    // Instruction i is wave i % W's.  (The LDS-DMA form of these loads issued
+    // four times slower.)  Lanes beyond the row read the row's first column again.
+    narrow_v4u creg[NIPW + NIIW];
     auto issue_cols = [&](int it) {
         if (it >= nrows)
             return;
         const int r = __builtin_amdgcn_readfirstlane(rowc_s[it].y & 0xffff);
         const int4* dsc = (const int4*)(smem + L.off_desc + (it % 3) * L.desc_size);
-        // first every descriptor this lane needs (LDS reads, all in flight together),
-        // then the loads; lanes beyond the row read the row's first column again
-        int2 dp[NIP], di[NII];
+        int qp[NIPW], qi[NIIW];
 #pragma unroll
-        for (int i = 0; i < NIP; ++i) {
-            const int c = CPI * i + lane / CH;
-            dp[i] = *(const int2*)&dsc[(c < r ? c : 0) * 2];
+        for (int t = 0; t < NIPW; ++t) {
+            const int c = CPI * (wave + W * t) + lane / CH;
+            qp[t] = dsc[(c < r ? c : 0) * 2].x;
         }
 #pragma unroll
-        for (int i = 0; i < NII; ++i) {
-            const int c = 32 * i + (lane >> 1);
-            di[i] = *(const int2*)&dsc[(c < r ? c : 0) * 2];
+        for (int t = 0; t < NIIW; ++t) {
+            const int c = 32 * (wave + W * t) + (lane >> 1);
+            qi[t] = dsc[(c < r ? c : 0) * 2].x;
         }
 #pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) {
+        for (int t = 0; t < NIPW; ++t) {
+            const int c = CPI * (wave + W * t) + lane / CH;
+            const int u = (lane % CH) ^ (c & (CH - 1));
+            creg[t] = *(const narrow_v4u*)((const char*)(P + qp[t]) + u * 16);
+        }
 #pragma unroll
-            for (int i = 0; i < NIP; ++i) {
-                const int c = CPI * i + lane / CH;
-                const int u = (lane % CH) ^ (c & (CH - 1));
-                const int q = (pc == 0 || pc * 16 < dp[i].y) ? dp[i].x + pc * 16 : dp[i].x;
-                creg[pc][i] = *(const narrow_v4u*)((const char*)(P + q) + u * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < NII; ++i) {
-                const int c = 32 * i + (lane >> 1);
-                const int h = (lane & 1) ^ ((c >> 2) & 1);
-                const int q = (pc == 0 || pc * 16 < di[i].y) ? di[i].x + pc * 16 : di[i].x;
-                creg[pc][NIP + i] = *(const narrow_v4u*)((const char*)(ids16 + q) + h * 16);
-            }
+        for (int t = 0; t < NIIW; ++t) {
+            const int c = 32 * (wave + W * t) + (lane >> 1);
+            const int h = (lane & 1) ^ ((c >> 2) & 1);
+            creg[NIPW + t] = *(const narrow_v4u*)((const char*)(ids16 + qi[t]) + h * 16);
         }
     };
     auto land_cols = [&](int it) {
@@ -377,23 +407,27 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
             return;
         unsigned char* cb = smem + L.off_cols + (it & 1) * L.cols_size;
 #pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) {
+        for (int t = 0; t < NIPW; ++t)
+            if (wave + W * t < NIP)
+                *(narrow_v4u*)(cb + (wave + W * t) * 1024 + lane * 16) = creg[t];
 #pragma unroll
-            for (int i = 0; i < NIP; ++i)
-                *(narrow_v4u*)(cb + pc * RP * PB + i * 1024 + lane * 16) = creg[pc][i];
-#pragma unroll
-            for (int i = 0; i < NII; ++i)
-                *(narrow_v4u*)(cb + L.ids_off + pc * RP * 32 + i * 1024 + lane * 16) = creg[pc][NIP + i];
-        }
+        for (int t = 0; t < NIIW; ++t)
+            if (wave + W * t < NII)
+                *(narrow_v4u*)(cb + L.ids_off + (wave + W * t) * 1024 + lane * 16) = creg[NIPW + t];
     };
     auto wait_loads = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     issue_desc(0);
     issue_desc(1);
     wait_loads();
+    __syncthreads();
     issue_cols(0);
     wait_loads();
     land_cols(0);
+    // the tie filter of row 0 (in the column buffer of row 1)
+    if (tid < 64)
+        reinterpret_cast<uint4*>(smem + L.off_cols + L.cols_size + L.off_tab)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
     BXH_PSTAMP(&prof, 0);
 
     int kprev = -1;       // the row updated just before (its P stores are not in the staged lines)
@@ -423,6 +457,7 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
         unsigned long long* key_run = (unsigned long long*)(rbuf + L.off_tab);
         int* id_run = (int*)(key_run + L.n2);
         int* rank_s = (int*)(rbuf + L.off_rank);
+        unsigned long long* part_s = part_all + (it & 1) * 16;
 
         // ---- decrease_preference + compute_reduced_costs (+ push) ----------
         struct Elem
@@ -434,7 +469,7 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
         unsigned long long key[NE];
 #pragma unroll
         for (int s = 0; s < NE; ++s) {
-            const int idx = lane + 64 * s;
+            const int idx = tid + T * s;
             v[s] = (Float)0;
             pown[s] = (Float)0;
             key[s] = ~0ull;
@@ -456,35 +491,33 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
                     cj = (Float)__longlong_as_double(((long long)(unsigned)d1.y << 32) | (unsigned)d1.x);
                 else
                     cj = (Float)__int_as_float(d1.x);
-                // where element t of the column sits in the staged copy
-                auto p_at = [&](int t) -> Float* {
-                    const int pc = t >> 4, tt = t & 15;
-                    const int u = (tt / EPC) ^ (idx & (CH - 1));
-                    return (Float*)(cbuf + pc * RP * PB + idx * PB + u * 16) + (tt % EPC);
+                // where element t (< 16) of the column sits in the staged copy
+                const int cb_off = L.off_cols + (it & 1) * L.cols_size; // (offsets from smem: the
+                auto p_at = [&](int t) -> int {                       //  accesses stay LDS accesses)
+                    const int u = (t / EPC) ^ (idx & (CH - 1));
+                    return cb_off + idx * PB + u * 16 + (t % EPC) * FS;
                 };
                 auto id_at = [&](int t) -> unsigned {
-                    const int pc = t >> 4, tt = t & 15;
-                    const int h = (tt >> 3) ^ ((idx >> 2) & 1);
-                    return *((const unsigned short*)(cbuf + L.ids_off + pc * RP * 32 + idx * 32 + h * 16) +
-                             (tt & 7));
+                    const int h = (t >> 3) ^ ((idx >> 2) & 1);
+                    return *((const unsigned short*)(cbuf + L.ids_off + idx * 32 + h * 16) + (t & 7));
                 };
                 // the slot the previous row has just stored: recomputed in the staged copy
                 {
                     const int sp = (int)slot_s[j];
-                    if (sp < NPC * 16 && sp < len && (int)(id_at(sp) & 0x7fffu) == kprev) {
+                    if (sp < 16 && sp < len && (int)(id_at(sp) & 0x7fffu) == kprev) {
                         const bool xbit = (x_s[j >> 5] >> (j & 31)) & 1u;
-                        Float* pp = p_at(sp);
-                        Float pv = *pp * theta;
+                        const int po_ = p_at(sp);
+                        Float pv = *(Float*)(smem + po_) * theta;
                         pv = pv + (xbit ? dprev : -dprev);
-                        *pp = pv;
+                        *(Float*)(smem + po_) = pv;
                     }
                 }
                 // P[e] *= theta (written back by affect)
                 Float po = 0;
-                if (own < NPC * 16) {
-                    Float* pp = p_at(own);
-                    po = *pp * theta;
-                    *pp = po;
+                if (own < 16) {
+                    const int po_ = p_at(own);
+                    po = *(Float*)(smem + po_) * theta;
+                    *(Float*)(smem + po_) = po;
                 }
                 Float spi = 0, sp = 0;
                 auto accumulate = [&](const NarrowPiece<Float>& pcs, int base, bool check_own) {
@@ -508,38 +541,36 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
                         }
                     }
                 };
+                {
+                    NarrowPiece<Float> pcs;
+                    const unsigned char* pl = cbuf + idx * PB;
 #pragma unroll
-                for (int pc = 0; pc < NPC; ++pc)
-                    if (pc == 0 || pc * 16 < len) {
-                        NarrowPiece<Float> pcs;
-                        const unsigned char* pl = cbuf + pc * RP * PB + idx * PB;
-#pragma unroll
-                        for (int u = 0; u < CH; ++u) {
-                            const uint4 w = *(const uint4*)(pl + ((u ^ (idx & (CH - 1))) * 16));
-                            if constexpr (FS == 8) {
-                                pcs.p[2 * u] = __longlong_as_double(((long long)w.y << 32) | w.x);
-                                pcs.p[2 * u + 1] = __longlong_as_double(((long long)w.w << 32) | w.z);
-                            } else {
-                                pcs.p[4 * u] = __uint_as_float(w.x);
-                                pcs.p[4 * u + 1] = __uint_as_float(w.y);
-                                pcs.p[4 * u + 2] = __uint_as_float(w.z);
-                                pcs.p[4 * u + 3] = __uint_as_float(w.w);
-                            }
+                    for (int u = 0; u < CH; ++u) {
+                        const uint4 w = *(const uint4*)(pl + ((u ^ (idx & (CH - 1))) * 16));
+                        if constexpr (FS == 8) {
+                            pcs.p[2 * u] = __longlong_as_double(((long long)w.y << 32) | w.x);
+                            pcs.p[2 * u + 1] = __longlong_as_double(((long long)w.w << 32) | w.z);
+                        } else {
+                            pcs.p[4 * u] = __uint_as_float(w.x);
+                            pcs.p[4 * u + 1] = __uint_as_float(w.y);
+                            pcs.p[4 * u + 2] = __uint_as_float(w.z);
+                            pcs.p[4 * u + 3] = __uint_as_float(w.w);
                         }
-                        const unsigned char* il = cbuf + L.ids_off + pc * RP * 32 + idx * 32;
-                        const uint4 ia = *(const uint4*)(il + (((idx >> 2) & 1) * 16));
-                        const uint4 ib = *(const uint4*)(il + ((((idx >> 2) & 1) ^ 1) * 16));
-                        pcs.id[0] = ia.x;
-                        pcs.id[1] = ia.y;
-                        pcs.id[2] = ia.z;
-                        pcs.id[3] = ia.w;
-                        pcs.id[4] = ib.x;
-                        pcs.id[5] = ib.y;
-                        pcs.id[6] = ib.z;
-                        pcs.id[7] = ib.w;
-                        accumulate(pcs, pc * 16, false);
                     }
-                for (int b = NPC * 16; b < len; b += 16) { // the rest of a long column: fetched now
+                    const unsigned char* il = cbuf + L.ids_off + idx * 32;
+                    const uint4 ia = *(const uint4*)(il + (((idx >> 2) & 1) * 16));
+                    const uint4 ib = *(const uint4*)(il + ((((idx >> 2) & 1) ^ 1) * 16));
+                    pcs.id[0] = ia.x;
+                    pcs.id[1] = ia.y;
+                    pcs.id[2] = ia.z;
+                    pcs.id[3] = ia.w;
+                    pcs.id[4] = ib.x;
+                    pcs.id[5] = ib.y;
+                    pcs.id[6] = ib.z;
+                    pcs.id[7] = ib.w;
+                    accumulate(pcs, 0, false);
+                }
+                for (int b = 16; b < len; b += 16) { // the rest of a long column: fetched now
                     NarrowPiece<Float> extra;
                     narrow_load_piece<Float>(P, ids16, q0 + b, extra);
                     accumulate(extra, b, true);
@@ -557,23 +588,30 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
 
         BXH_PSTAMP(&prof, 2);
         // ---- selection without sorting (see sweep_kernel_v2): class counts,
-        // the extreme keys and the keys next to the class borders ------------
+        // the extreme keys and the keys next to the class borders; the waves'
+        // partial results meet in LDS ----------------------------------------
         bool fast = false;
         int f_mode = 0, f_nN = 0, f_nZ = 0;
         unsigned long long f_thr = 0ull;
         Float f_d = 0, f_newpi = 0;
         bool f_pich = false;
+        const unsigned long long K0 = order_key<Float>((Float)0, maximize);
+        // an equality row (or bmin == bmax) that selects exactly one element only asks for
+        // the two smallest keys: the other extreme keys are not reduced then
+        const bool only_two = (kind == 0 || kind == 2 || row_bmin == row_bmax) &&
+                              min(row_bmin + row_csize, r) - 1 == 0;
         if (r >= 2) {
-            const unsigned long long K0 = order_key<Float>((Float)0, maximize);
-            reinterpret_cast<uint4*>(filt_s)[lane] = make_uint4(0u, 0u, 0u, 0u); // 256 words
             unsigned long long A = ~0ull, A2 = ~0ull, B = ~0ull, C = ~0ull, D = ~0ull;
             int cN = 0, cZ = 0;
-            bool flagged[NE];
+            bool flagged = false;
 #pragma unroll
             for (int s = 0; s < NE; ++s) {
-                const bool have = lane + 64 * s < r;
+                const bool have = tid + T * s < r;
                 const unsigned long long kk = key[s];
-                flagged[s] = have && narrow_filter_insert(filt_s, kk);
+                // a flagged key MAY equal an earlier one: the row then takes the sort
+                // path, which is always right
+                if (have)
+                    flagged |= narrow_filter_insert(filt_s, kk);
                 const bool isN = have && kk < K0, isZ = have && kk == K0, isS = have && kk > K0;
                 cN += __popcll(__ballot(isN));
                 cZ += __popcll(__ballot(isZ));
@@ -586,31 +624,56 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
                 C = umin64(C, isN ? ~kk : ~0ull);
                 D = umin64(D, isS ? kk : ~0ull);
             }
-            // a flagged key MAY equal an earlier one: looked up in the whole row (rare)
-            bool anytie = false;
-#pragma unroll
-            for (int s = 0; s < NE; ++s) {
-                unsigned long long pending = __ballot(flagged[s]);
-                while (pending && !anytie) {
-                    const int src = __ffsll((long long)pending) - 1;
-                    pending &= pending - 1;
-                    const unsigned long long fk =
-                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key[s] >> 32), src) << 32) |
-                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key[s], src);
-                    int same = 0;
-#pragma unroll
-                    for (int s2 = 0; s2 < NE; ++s2)
-                        same += __popcll(__ballot(lane + 64 * s2 < r && key[s2] == fk));
-                    if (same >= 2)
-                        anytie = true;
-                }
-            }
+            const bool wtie = __ballot(flagged) != 0ull;
             const unsigned long long ownA = A;
-            wave_umin64x4(A, B, C, D);
+            if (only_two)
+                A = wave_umin64(A);
+            else
+                wave_umin64x4(A, B, C, D);
             unsigned long long E = ownA == A ? A2 : ownA;
             E = wave_umin64(E);
-            const unsigned long long g1 = A, gx = ~B, gxN = ~C, gnS = D;
-            const int nN = cN, nZ = cZ;
+            if (lane == 0) {
+                const unsigned long long cnt = ((unsigned long long)(unsigned)cN << 32) | (unsigned)cZ;
+                if (W > 1) {
+                    if (!only_two) {
+                        atomicMax(&part_s[8], ~B);
+                        atomicMax(&part_s[9], ~C);
+                        atomicMin(&part_s[10], D);
+                    }
+                    atomicMin(&part_s[13], A);
+                    atomicAdd(&part_s[11], cnt);
+                    if (wtie)
+                        atomicOr(&part_s[12], 1ull);
+                } else {
+                    part_s[8] = ~B;
+                    part_s[9] = ~C;
+                    part_s[10] = D;
+                    part_s[13] = A;
+                    part_s[11] = cnt;
+                    part_s[12] = wtie ? 1ull : 0ull;
+                }
+                part_s[wave * 2] = A;
+                part_s[wave * 2 + 1] = E;
+            }
+        }
+        __syncthreads();
+        if (W > 1 && tid == 0) // the other set, for the next row
+            part_reset(part_all + ((it + 1) & 1) * 16);
+        if (r >= 2) {
+            const unsigned long long g1 = uniform_u64(part_s[13]);
+            const unsigned long long gx = uniform_u64(part_s[8]), gxN = uniform_u64(part_s[9]),
+                                     gnS = uniform_u64(part_s[10]);
+            const unsigned long long cnt = uniform_u64(part_s[11]);
+            const int nN = (int)(cnt >> 32), nZ = (int)(cnt & 0xffffffffu);
+            const bool anytie = uniform_u64(part_s[12]) != 0ull;
+            // second smallest key: the minimum over the waves of "second smallest of
+            // the wave that holds g1, smallest of the others"
+            unsigned long long cnd = ~0ull;
+            if (lane < W) {
+                const unsigned long long a1 = part_s[lane * 2], a2 = part_s[lane * 2 + 1];
+                cnd = a1 == g1 ? a2 : a1;
+            }
+            const unsigned long long E2 = wave_umin64(cnd);
             bool ok = !anytie;
             const unsigned saved_rng = rng.s;
             int sel = 0;
@@ -659,7 +722,7 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
                     if (rank == 0)
                         return g1;
                     if (rank == 1)
-                        return E;
+                        return E2;
                     if (rank == r - 1)
                         return gx;
                     if (nN > 0 && rank == nN - 1)
@@ -711,24 +774,25 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
         }
 
         BXH_PSTAMP(&prof, 3);
-        // the columns read ahead must have landed before this row's stores to
+        // the columns read ahead must have arrived before this row's stores to
         // the same lines are issued
         wait_loads();
         BXH_PSTAMP(&prof, 4);
+        // the tie filter of the next row lives where this row's lines were read from
+        if (tid < 64)
+            reinterpret_cast<uint4*>(cbuf + L.off_tab)[tid] = make_uint4(0u, 0u, 0u, 0u);
 
         if (fast) {
             const int mode = f_mode;
             const Float d = f_d;
-            if (lane == 0) {
-                if (mode == 2) {
-                    pi_s[k] = f_newpi;
-                    if (f_pich)
-                        misc_s[MS_PICH] = 1;
-                }
+            if (tid == 0 && mode == 2) {
+                pi_s[k] = f_newpi;
+                if (f_pich)
+                    misc_s[MS_PICH] = 1;
             }
 #pragma unroll
             for (int s = 0; s < NE; ++s) {
-                const int idx = lane + 64 * s;
+                const int idx = tid + T * s;
                 if (idx < r) {
                     const int j = el[s].jw & 0x7fffffff;
                     const int pe = el[s].pe;
@@ -754,43 +818,43 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
             // ---- calculator_sort: sort, then shuffle every run of equal values
 #pragma unroll
             for (int s = 0; s < NE; ++s)
-                if (lane + 64 * s < r)
-                    val_s[lane + 64 * s] = v[s];
-            if (lane == 0)
+                if (tid + T * s < r)
+                    val_s[tid + T * s] = v[s];
+            if (tid == 0)
                 misc_s[MS_TIE] = 0;
             __syncthreads();
             const int n2 = next_pow2(r < 2 ? 2 : r);
-            if (r <= 128) {
+            if (r <= 2 * T) {
                 if (r > 1) {
                     run_merge_sort<Float>(val_s, r, maximize, key_run, id_run, key_s, id_s, &prof);
                 } else {
-                    if (lane == 0) {
+                    if (tid == 0) {
                         key_s[0] = order_key<Float>(val_s[0], maximize);
                         id_s[0] = 0;
                     }
                     __syncthreads();
                 }
             } else {
-                for (int i = lane; i < n2; i += 64) {
+                for (int i = tid; i < n2; i += T) {
                     key_s[i] = i < r ? order_key<Float>(val_s[i], maximize) : ~0ull;
                     id_s[i] = i;
                 }
                 __syncthreads();
                 bitonic_sort(key_s, id_s, n2);
             }
-            for (int i = lane; i + 1 < r; i += 64)
+            for (int i = tid; i + 1 < r; i += T)
                 if (key_s[i] == key_s[i + 1])
                     misc_s[MS_TIE] = 1;
             __syncthreads();
             bool shuffled = false;
-            if (misc_s[MS_TIE] && r <= 128) {
+            if (misc_s[MS_TIE] && r <= 2 * T) {
                 unsigned stt = rng.s;
                 shuffled = parallel_tie_shuffle(key_s, id_s, r, &stt, pb.lcg_pow, (int*)key_run,
                                                 (int*)key_run + L.n2, id_run, misc_s + MS_WAVES);
                 if (shuffled)
                     rng.s = stt;
             }
-            if (lane == 0) {
+            if (tid == 0) {
                 if (misc_s[MS_TIE] && !shuffled) {
                     int b0 = 0;
                     for (int i = 1; i <= r; ++i) {
@@ -851,14 +915,14 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
             rng.s = (unsigned)misc_s[MS_RNG];
             const int sel = misc_s[MS_SEL];
             const Float d = *d_s;
-            for (int i = lane; i < r; i += 64)
+            for (int i = tid; i < r; i += T)
                 rank_s[id_s[i]] = i;
             __syncthreads();
-            for (int i = lane; i < r; i += 64)
+            for (int i = tid; i < r; i += T)
                 stale_s[i] = val_s[id_s[i]]; // R[i].value after the sort
 #pragma unroll
             for (int s = 0; s < NE; ++s) {
-                const int idx = lane + 64 * s;
+                const int idx = tid + T * s;
                 if (idx < r) {
                     const int j = el[s].jw & 0x7fffffff;
                     const int pe = el[s].pe;
@@ -874,34 +938,34 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
                     slot_s[j] = (unsigned char)el[s].own;
                 }
             }
-            __syncthreads();
+            __syncthreads(); // (the sort path's buffers are done with: the lines of the next row go there)
             dprev = d;
             BXH_PSTAMP(&prof, 6);
         }
         kprev = k;
-        land_cols(it + 1); // (the sort path's buffers, in the same place, are done with)
-
+        land_cols(it + 1);
+        __syncthreads(); // x, pi, the slot bytes and the staged lines of the next row are in place
         BXH_PSTAMP(&prof, 7);
     }
 
     // ---- write back, then compute_violated_constraints ---------------------
     __syncthreads();
-    for (int i = lane; i < pb.m; i += 64)
+    for (int i = tid; i < pb.m; i += T)
         pig[i] = pi_s[i];
-    for (int i = lane; i < 2 * pb.nwords; i += 64)
+    for (int i = tid; i < 2 * pb.nwords; i += T)
         xg[i] = x_s[i];
-    for (int i = lane; i <= pb.rmax; i += 64)
+    for (int i = tid; i <= pb.rmax; i += T)
         staleg[i] = stale_s[i];
     if (ord == 7) // pi_sign_change keeps the shuffled R
-        for (int i = lane; i < nrows; i += 64)
+        for (int i = tid; i < nrows; i += T)
             vlist[i] = rows_s[i];
 
-    // row activities from the set bits of x: every lane takes words of x, four
+    // row activities from the set bits of x: every thread takes words of x, four
     // columns at a time (their descriptor loads, then their row ids, together)
-    for (int i = lane; i <= pb.m; i += 64)
+    for (int i = tid; i <= pb.m; i += T)
         act_s[i] = 0;
     __syncthreads();
-    for (int w = lane; w < 2 * pb.nwords; w += 64) {
+    for (int w = tid; w < 2 * pb.nwords; w += T) {
         unsigned word = x_s[w];
         while (word) {
             int jj[4], q0[4], ln[4];
@@ -910,6 +974,8 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
                 if (word) {
                     jj[u] = w * 32 + (__ffs((int)word) - 1);
                     word &= word - 1;
+                    if (jj[u] >= pb.n)
+                        jj[u] = -1;
                 } else
                     jj[u] = -1;
             }
@@ -946,26 +1012,45 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
     }
     __syncthreads();
     int cnt = 0;
-    for (int c = 0; c < pb.m; c += 64) {
-        const int k = c + lane;
-        bool f = false;
-        if (k < pb.m) {
-            const int av = act_s[k];
-            f = !(pb.bmin[k] <= av && av <= pb.bmax[k]);
+    {
+        int* scratch_s = misc_s + MS_WAVES;
+        for (int c = 0; c < pb.m; c += T) {
+            const int kq = c + tid;
+            bool f = false;
+            if (kq < pb.m) {
+                const int av = act_s[kq];
+                f = !(pb.bmin[kq] <= av && av <= pb.bmax[kq]);
+            }
+            const unsigned long long mask = __ballot(f);
+            const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+            int off = 0, tot = __popcll(mask);
+            if (W > 1) {
+                if (lane == 0)
+                    scratch_s[wave] = __popcll(mask);
+                __syncthreads();
+                tot = 0;
+                for (int w = 0; w < W; ++w) {
+                    const int cw = scratch_s[w];
+                    if (w < wave)
+                        off += cw;
+                    tot += cw;
+                }
+            }
+            if (f)
+                out_list[cnt + off + prefix] = kq;
+            cnt += tot;
+            if (W > 1)
+                __syncthreads();
         }
-        const unsigned long long mask = __ballot(f);
-        if (f)
-            out_list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = k;
-        cnt += __popcll(mask);
     }
 
     BXH_PSTAMP(&prof, 8);
 #ifdef BXH_PROFILE
-    if (lane == 0)
+    if (tid == 0)
         for (int i = 0; i < 16; ++i)
             st.prof[(size_t)inst * 32 + i] += prof.acc[i];
 #endif
-    if (lane == 0) {
+    if (tid == 0) {
         if (!keep)
             st.vcount[inst] = cnt;
         DevStatus s = st.status[inst];

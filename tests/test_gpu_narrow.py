@@ -1,6 +1,7 @@
-"""-m gpu: the one-wave-per-instance kernel for short rows
-(baryonyx_amd/csrc/bxh_narrow.hpp; rows of at most 256 elements, read-ahead of
-the next row's columns with the previous row's P store recomputed in registers)
+"""-m gpu: the kernel for short rows (baryonyx_amd/csrc/bxh_narrow.hpp: one or
+four waves per instance, rows of at most 256 elements, the next row's column
+lines read ahead and staged in LDS, the previous row's P store recomputed in the
+staged copy)
 against the oracle, sweep by sweep, bit-exact on x / pi / P / violated rows /
 engine state:
 
@@ -23,11 +24,13 @@ from test_gpu_parity import CASES, ORDER_CASES, _custom, run_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def narrow_env(monkeypatch):
+@pytest.fixture(autouse=True, params=["1", "4"], ids=["1wave", "4waves"])
+def narrow_env(request, monkeypatch):
+    """One wave per instance, and four (one per SIMD of the CU, two barriers per row)."""
     monkeypatch.delenv("BXH_GROUPS", raising=False)
     monkeypatch.delenv("BXH_FORCE_V1", raising=False)
     monkeypatch.setenv("BXH_NARROW", "1")
+    monkeypatch.setenv("BXH_NARROW_W", request.param)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -99,7 +102,6 @@ def test_narrow_rows_sharing_columns(oracle, bxh, kind, order):
 def test_narrow_baseline_shapes_many_instances(oracle, bxh, name, monkeypatch):
     """scp41 / aa04 shapes with 70 instances (more waves than one per CU on a
     quarter of the chip), and the kernel chosen by bxh_create itself."""
-    if name == "c1":  # (rows of up to 64 elements go to this kernel by default)
-        monkeypatch.delenv("BXH_NARROW", raising=False)
+    monkeypatch.delenv("BXH_NARROW", raising=False)
     inst = synth.config_c1("int") if name == "c1" else synth.config_c3("int")
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=70, sweeps=4, push_at=(2,), expect_form=5)
