@@ -52,11 +52,20 @@ struct DevBuf
         p = nullptr;
         count = 0;
     }
+    // Every buffer starts as zeros (hipMalloc hands out whatever the last owner
+    // left there; a scratch array read before its first write must not depend on
+    // that).  BXH_POISON=1 fills with 0xA5 instead: a diagnostic for such reads.
     hipError_t alloc(size_t n)
     {
         release();
         count = n;
-        return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
+        if (e != hipSuccess)
+            return e;
+        static const bool poison = std::getenv("BXH_POISON") != nullptr;
+        static const bool raw = std::getenv("BXH_NO_ZERO") != nullptr; // (diagnostic)
+        return raw ? hipSuccess : hipMemset(p, poison ? 0xA5 : 0, bytes);
     }
     hipError_t upload(const std::vector<T>& v)
     {
@@ -1427,6 +1436,15 @@ bxh_create_device(const bxh_problem* pb,
     hipError_t e0 = hipSetDevice(device);
     if (e0 != hipSuccess)
         return fail(BXH_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e0));
+    // The caller's arrays may have been produced on any stream (a copy from
+    // pageable host memory returns before the data is on the device): wait for
+    // everything queued on the device before the build kernels, which run on the
+    // handle's own non-blocking stream, read them.
+    {
+        hipError_t es = hipDeviceSynchronize();
+        if (es != hipSuccess)
+            return fail(BXH_ERR_DEVICE, std::string("hipDeviceSynchronize: ") + hipGetErrorString(es));
+    }
 
     bxh_handle h = new (std::nothrow) bxh_handle_s;
     if (!h)

@@ -144,7 +144,9 @@ int bxh_create(const bxh_problem* pb,
  * by all `batch` instances -- the reference rebuilds them per worker thread
  * (itm-optimizer-common.hpp:649-653); no host loop touches the elements
  * (2e9 of them at the 100k x 1M shape).  Kinds BXH_EQ_01 .. BXH_INEQ_101,
- * linear objective (n_quad == 0).  pb->factor may be NULL (all +1). */
+ * linear objective (n_quad == 0).  pb->factor may be NULL (all +1).  The call
+ * first waits for all work queued on the device (the arrays may come from any
+ * stream) and has copied what it needs when it returns. */
 int bxh_create_device(const bxh_problem* pb_on_device,
                       int kind,
                       int float_type,

@@ -186,8 +186,10 @@ def test_device_built_matrix_matches_oracle(oracle, bxh, case, groups, monkeypat
         for b, s in enumerate(orcs):
             rr = s.sweep(float(kappa[b]), delta, 0.5, is_push=push, obj_amp=5.0 if push else 0.0)
             tag = f"sweep {it} inst {b}"
-            assert st["remaining"][b] == rr, tag
-            assert np.array_equal(dev.get_x(b), s.get_x()), tag + " x"
+            same_x = np.array_equal(dev.get_x(b), s.get_x())
+            assert st["remaining"][b] == rr, (tag, "x equal" if same_x else "x differs",
+                                             list(dev.violated(b)), list(s.violated()))
+            assert same_x, tag + " x"
             assert np.array_equal(dev.violated(b), s.violated()), tag + " violated"
             pd, po = dev.get_pi(b), s.get_pi()
             assert bits_equal(pd, po), f"{tag} pi first diff at {first_diff(pd, po)}"
