@@ -1117,6 +1117,13 @@ optimize_problem(const context& ctx, const problem& pb)
 
     // `thread` workers -> one batch of solver instances (64 when unset)
     const int workers = p.thread <= 0 ? 64 : p.thread;
+    // The random cost norm (itm-common.hpp:1221-1326) gives every worker of the
+    // reference its own cost vector, drawn from its own engine
+    // (optimize_functor::operator(), itm-optimizer-common.hpp:633-638).  One batch
+    // of instances shares one cost vector here: refuse rather than run something
+    // else.  (solve(), one instance, takes it.)
+    if (p.cost_norm == solver_parameters::cost_norm_type::random && workers > 1)
+        throw solver_failure(solver_error_tag::no_solver_available);
 
     recorder<Float> best_recorder(rng, workers, cost, cost_constant, variables, constraints,
                                   p.init_population_size, maximize);

@@ -183,6 +183,8 @@ def kernel_label(form):
         return "bxh::sweep_kernel_v2 (staged, 1 workgroup / instance)"
     if form == 3:
         return "bxh::sweep_kernel_z"
+    if form == 5:
+        return "bxh::sweep_kernel_narrow (short rows: one or four waves / instance)"
     if form > 100:
         return f"bxh::sweep_kernel_wide ({form - 100} workgroups / instance share every row)"
     if 20 < form < 40:

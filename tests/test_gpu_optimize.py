@@ -125,3 +125,16 @@ def test_optimize_over_several_devices_is_the_same_run(oracle, tmp_path, monkeyp
     assert (res1.value, res1.loop, res1.remaining_constraints) == (res3.value, res3.loop, res3.remaining_constraints)
     ores, otr = oracle.optimize(inst, 1, oracle.default_params(sort_mode=1, **okw), thread=8, rounds=250)
     assert np.array_equal(tr3["pop_hash"], otr["pop_hash"]) and np.array_equal(tr3["worker_rng"], otr["worker_rng"])
+
+
+def test_optimize_refuses_the_random_cost_norm(tmp_path):
+    """Every worker of the reference's optimize draws its OWN random-norm cost
+    vector (itm-optimizer-common.hpp:633-638); the batch shares one, so optimize
+    with more than one worker says so instead of running something else."""
+    path = str(tmp_path / "p.lp")
+    synth.write_lp(synth.make_scp(40, 200, 0.08, "int", 5), path)
+    with pytest.raises(RuntimeError, match="solver_failure"):
+        H.run(path, 1, H.default_params(seed=3, thread=4, cost_norm=1, sweep_budget=10, time_limit=5.0))
+    res, _ = H.run(path, 1, H.default_params(seed=3, thread=1, cost_norm=1, sweep_budget=50, time_limit=5.0))
+    assert res.status in (0, 3)
+
