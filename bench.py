@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="wall budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--exchange-every", type=int, default=8,
+                    help="ranks > 1: allreduce(min) of the incumbent + broadcast of its x every T steps "
+                         "(inside the timed region) and once at the end; 0 = at the end only")
     ap.add_argument("--e2e-rounds", type=int, default=100,
                     help="rounds of the end-to-end baryonyx::optimize run next to the oracle's (0 = skip)")
     return ap.parse_args()
@@ -558,9 +561,37 @@ def main():
     barrier()
     dev.kernel_time(reset=True)
     st0 = dev.status()
+    # the exchange step of the restart pool: every T steps the ranks
+    # agree on the incumbent -- allreduce(min) of the objective, broadcast of the
+    # winner's x (baryonyx_amd/dist.py) -- inside the timed region
+    incumbent = {"value": np.inf, "x": None, "exchanges": 0}
+
+    def local_best():
+        st = dev.status()
+        best, best_b = np.inf, -1
+        for b in range(wl.batch):
+            if st["remaining"][b] == 0:
+                v = wl.objective(b)
+                if v < best:
+                    best, best_b = v, b
+        return best, best_b
+
+    def exchange():
+        from baryonyx_amd.dist import reduce_incumbent
+        best, best_b = local_best()
+        if incumbent["x"] is not None and incumbent["value"] <= best:
+            best, xw = incumbent["value"], incumbent["x"]
+        else:
+            xw = dev.get_x(best_b) if best_b >= 0 else np.zeros(dev.nwords, np.uint64)
+        val, xall, _ = reduce_incumbent(best, xw, device="cpu" if share else "cuda")
+        incumbent["value"], incumbent["x"] = val, xall
+        incumbent["exchanges"] += 1
+
     t0 = time.perf_counter()
     for k in range(args.steps):
         wl.step(args.warmup + k)
+        if world > 1 and args.exchange_every > 0 and (k + 1) % args.exchange_every == 0:
+            exchange()
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, launches = dev.kernel_time()
@@ -587,9 +618,8 @@ def main():
                 best, best_b = v, b
     best_all = best
     if world > 1:
-        from baryonyx_amd.dist import reduce_incumbent
-        xw = dev.get_x(best_b) if best_b >= 0 else np.zeros(dev.nwords, np.uint64)
-        best_all, _, _ = reduce_incumbent(best, xw, device="cpu" if share else "cuda")
+        exchange()
+        best_all = incumbent["value"]
 
     if rank == 0:
         # algorithmic bytes: B(k) summed on the device over every
@@ -618,6 +648,8 @@ def main():
                 "row_updates": rows_all,
                 "rows_in_last_sweep": [int(v) for v in st1["rows_in_sweep"][:4]],
                 "best_objective": None if not np.isfinite(best_all) else float(best_all),
+                "incumbent_exchanges": incumbent["exchanges"],
+                "world_size": world,
             },
             "roofline": {
                 "bound": "hbm",

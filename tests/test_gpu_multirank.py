@@ -29,7 +29,7 @@ def test_two_ranks_share_the_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--cpu-seconds", "0"]
+           "--cpu-seconds", "0", "--exchange-every", "2"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -40,3 +40,6 @@ def test_two_ranks_share_the_gpu():
     assert rec["config"]["row_updates"] == 2 * 6 * 64 * 1000
     assert rec["value"] > 0 and rec["roofline"]["frac"] > 0
     assert rec["config"]["best_objective"] is None or rec["config"]["best_objective"] > 0
+    # the incumbent went round (allreduce(min) + broadcast of the winner's x) every
+    # second step inside the timed region and once at the end
+    assert rec["config"]["incumbent_exchanges"] == 4 and rec["config"]["world_size"] == 2
