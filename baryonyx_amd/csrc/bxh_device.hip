@@ -989,7 +989,7 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->bneg.upload(bneg));
     HIP_TRY(h->fac_csr.upload(fac_csr));
     {
-        std::vector<unsigned> pw(1026);
+        std::vector<unsigned> pw(bxh::WIDE_LCG_POW); // (the short rows need 1026 of them)
         unsigned long long v = 1;
         for (size_t k = 0; k != pw.size(); ++k) {
             pw[k] = static_cast<unsigned>(v);
@@ -1574,7 +1574,7 @@ bxh_create_device(const bxh_problem* pb,
         return fail(BXH_ERR_INVALID, "constraint with min > max");
     cnt.release(); // (1 GB at the XL shape: gone before the instances are allocated)
     {
-        std::vector<unsigned> pw(1026);
+        std::vector<unsigned> pw(bxh::WIDE_LCG_POW); // (the short rows need 1026 of them)
         unsigned long long v = 1;
         for (size_t k = 0; k != pw.size(); ++k) {
             pw[k] = static_cast<unsigned>(v);

@@ -72,7 +72,7 @@ struct DevProblem
     const int* q_id;           // [n_quad]
     const void* q_factor;      // [n_quad] Float
     const double* row_bytes;   // [m] algorithmic bytes of one update of row k
-    const unsigned* lcg_pow;   // [1026] 16807^k mod (2^31 - 1): jumps of minstd_rand0
+    const unsigned* lcg_pow;   // [32770] 16807^k mod (2^31 - 1): jumps of minstd_rand0
 };
 
 struct DevStatus // == bxh_status

@@ -34,6 +34,7 @@ namespace bxh {
 constexpr int WIDE_T = 512;      // threads of a workgroup
 constexpr int WIDE_TILE = 32;    // columns a wave streams together
 constexpr int WIDE_SMALL = 1024; // rows up to this length are sorted in LDS
+constexpr int WIDE_LCG_POW = 32770; // entries of DevProblem::lcg_pow (bxh_create uploads that many)
 constexpr int WIDE_ISLOT = 80;   // bytes of an index slot (16 int32 + pad)
 
 template<typename Float>
@@ -112,6 +113,170 @@ wide_lds(int G, int chmax, int fsize, int ring)
     o = al(o + p.union_bytes);
     p.total = o;
     return p;
+}
+
+// ---------------------------------------------------------------------------
+// The sort of a long row (more than WIDE_SMALL elements) with ties.
+//
+// bitonic_sort() over (key, id) pairs in global memory costs a barrier and a
+// round of global loads / stores per compare-exchange step (120 steps for 32768
+// pairs).  Here every step whose partner distance is below the chunk length C
+// runs on a chunk held in LDS (keys in `lk`, ids in `li`, C pairs): the pairs go
+// through global memory only for the few steps with a longer distance.  Same
+// network, same result: the unique order "by key, then by row-local id".
+__device__ inline void
+wide_sort_big(unsigned long long* gkey, int* gid, int n2, unsigned long long* lk, int* li, int C)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    auto cmpx = [&](unsigned long long& ka, int& ia, unsigned long long& kb, int& ib, bool asc) {
+        const bool gt = (ka > kb) || (ka == kb && ia > ib);
+        if (gt == asc) {
+            const unsigned long long tk = ka;
+            ka = kb;
+            kb = tk;
+            const int ti = ia;
+            ia = ib;
+            ib = ti;
+        }
+    };
+    // steps j = jtop .. 1 of stage k on the chunk that starts at pair c0 (in LDS)
+    auto local_steps = [&](int c0, int k, int jtop) {
+        for (int j = jtop; j > 0; j >>= 1) {
+            for (int t = tid; t < (C >> 1); t += T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool asc = ((c0 + i) & k) == 0;
+                unsigned long long ka = lk[i], kb = lk[l];
+                int ia = li[i], ib = li[l];
+                const unsigned long long ka0 = ka;
+                const int ia0 = ia;
+                cmpx(ka, ia, kb, ib, asc);
+                if (ka != ka0 || ia != ia0) {
+                    lk[i] = ka;
+                    li[i] = ia;
+                    lk[l] = kb;
+                    li[l] = ib;
+                }
+            }
+            __syncthreads();
+        }
+    };
+    auto load_chunk = [&](int c0) {
+        for (int i = tid; i < C; i += T) {
+            lk[i] = gkey[c0 + i];
+            li[i] = gid[c0 + i];
+        }
+        __syncthreads();
+    };
+    auto store_chunk = [&](int c0) {
+        for (int i = tid; i < C; i += T) {
+            gkey[c0 + i] = lk[i];
+            gid[c0 + i] = li[i];
+        }
+        __syncthreads();
+    };
+    // stages k <= C: whole chunks
+    for (int c0 = 0; c0 < n2; c0 += C) {
+        load_chunk(c0);
+        for (int k = 2; k <= C; k <<= 1)
+            local_steps(c0, k, k >> 1);
+        store_chunk(c0);
+    }
+    // stages k > C: the long distances in global memory, the rest in LDS again
+    for (int k = C << 1; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j >= C; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool asc = (i & k) == 0;
+                unsigned long long ka = gkey[i], kb = gkey[l];
+                int ia = gid[i], ib = gid[l];
+                const unsigned long long ka0 = ka;
+                const int ia0 = ia;
+                cmpx(ka, ia, kb, ib, asc);
+                if (ka != ka0 || ia != ia0) {
+                    gkey[i] = ka;
+                    gid[i] = ia;
+                    gkey[l] = kb;
+                    gid[l] = ib;
+                }
+            }
+            __syncthreads();
+        }
+        for (int c0 = 0; c0 < n2; c0 += C) {
+            load_chunk(c0);
+            local_steps(c0, k, C >> 1);
+            store_chunk(c0);
+        }
+    }
+}
+
+// std::shuffle of ONE run of equal keys (ids[0 .. L) in LDS) by all threads:
+// the engine is a linear congruential one, so every position works out its own
+// swap partner from draw number `1 + d` (libstdc++'s pairwise scheme, see
+// parallel_tie_shuffle), and the swaps are applied by tracing every final
+// position back through them.  Returns false (nothing changed) when a draw would
+// have been rejected -- the caller then shuffles the run serially.  jt / out:
+// L ints of LDS each.  *state is advanced by L / 2 draws.  Needs L / 2 + 1 <
+// pow_n (entries of lcg_pow).
+__device__ inline bool
+wide_run_shuffle(int* ids, int L, unsigned* state, const unsigned* lcg_pow, int* jt, int* out,
+                 int* flag_s)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    const unsigned st0 = *state;
+    const bool even = (L & 1) == 0;
+    if (tid == 0)
+        *flag_s = 0;
+    __syncthreads();
+    bool reject = false;
+    for (int i = tid; i < L; i += T) {
+        int jv = 0;
+        if (i >= 1) {
+            unsigned urange;
+            int d, half = 0;
+            unsigned b1 = 2;
+            if (even && i == 1) {
+                d = 0;
+                urange = 1u;
+            } else {
+                const int i0 = even ? (i & ~1) : (((i - 1) & ~1) + 1); // first index of the pair
+                d = even ? (i >> 1) : ((i - 1) >> 1);
+                half = i - i0;
+                b1 = (unsigned)i0 + 2u;
+                urange = ((unsigned)i0 + 1u) * b1 - 1u;
+            }
+            const unsigned urngrange = 2147483645u;
+            const unsigned uerange = urange + 1u;
+            const unsigned scaling = urngrange / uerange;
+            const unsigned past = uerange * scaling;
+            const unsigned raw = lcg_jump(lcg_pow, st0, d + 1) - 1u;
+            if (raw >= past)
+                reject = true;
+            const unsigned x = raw / scaling;
+            jv = (even && i == 1) ? (int)x : (half == 0 ? (int)(x / b1) : (int)(x % b1));
+        }
+        jt[i] = jv;
+    }
+    if (reject)
+        *flag_s = 1;
+    __syncthreads();
+    if (*flag_s)
+        return false;
+    for (int p = tid; p < L; p += T) {
+        int pos = p;
+        for (int i = L - 1; i >= 1; --i) {
+            const int j = jt[i];
+            pos = pos == i ? j : (pos == j ? i : pos);
+        }
+        out[p] = ids[pos];
+    }
+    __syncthreads();
+    for (int p = tid; p < L; p += T)
+        ids[p] = out[p];
+    *state = lcg_jump(lcg_pow, st0, L >> 1);
+    __syncthreads();
+    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -564,7 +729,9 @@ wide_sync(unsigned* cnt, unsigned target, unsigned* err, int* dead_s)
 enum
 {
     WM_DEAD = 96, // a partner timed out: leave the sweep
-    WM_TNP = 97   // longest column (in pieces) of this workgroup's part of the row
+    WM_TNP = 97,  // longest column (in pieces) of this workgroup's part of the row
+    WM_TAKE = 100, // long tied row: where thread 0's serial shuffle takes over (a run beyond LDS)
+    WM_FLAG = 101  // ... a draw of a run's shuffle was rejected
 };
 
 // One sweep of every instance: compute_order::run / push_and_run
@@ -1409,11 +1576,246 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                     bid[i] = i;
                 }
                 __syncthreads();
-                bitonic_sort(bkey, bid, n2);
+                // LDS scratch of this path: the pi window (refilled at the start of every
+                // tile set) and the staging slots (idle outside the column sums)
+                const int ring_bytes = wp.ring * (int)sizeof(Float);
+                unsigned long long* lk = (unsigned long long*)ring_s;
+                int* li = (int*)uni;
+                int C = 512;
+                while (C * 2 <= n2 && C * 2 * 8 <= ring_bytes && C * 2 * 4 <= lp.union_bytes)
+                    C *= 2;
+                if (C * 8 <= ring_bytes && C * 4 <= lp.union_bytes && C <= n2)
+                    wide_sort_big(bkey, bid, n2, lk, li, C);
+                else
+                    bitonic_sort(bkey, bid, n2);
                 for (int i = tid; i + 1 < r; i += T)
                     if (bkey[i] == bkey[i + 1])
                         misc_s[MS_TIE] = 1;
                 __syncthreads();
+                // ---- the tied runs.  Draw number g of the row's engine is a jump of the
+                // linear congruential engine, and a run of L elements takes L / 2 draws
+                // unless one is rejected: so every run's first draw is known from the run
+                // lengths, the runs can be shuffled side by side (one wave each: runs of
+                // up to 512; all threads: up to 2048), and one pass over all draws tells
+                // whether -- and in which run first -- a rejection shifts the stream; from
+                // that run on thread 0 shuffles serially, as for rows with too many runs.
+                int serial_head = 0;     // first position left to thread 0's serial shuffle
+                unsigned serial_state = rng.s;
+                bool runs_listed = false;
+                if (misc_s[MS_TIE]) {
+                    int* rl_head = (int*)uni;
+                    const int RCAP = lp.union_bytes / 12;
+                    int* rl_len = rl_head + RCAP;
+                    int* rl_base = rl_len + RCAP;
+                    // ordered lists of the runs' first and last positions
+                    int nh = 0, nt = 0;
+                    for (int pass = 0; pass < 2; ++pass) {
+                        int base = 0;
+                        for (int c0 = 0; c0 < r; c0 += T) {
+                            const int i = c0 + tid;
+                            bool f = false;
+                            if (i < r) {
+                                const unsigned long long ki = bkey[i];
+                                const bool eq_next = i + 1 < r && bkey[i + 1] == ki;
+                                const bool eq_prev = i > 0 && bkey[i - 1] == ki;
+                                f = pass == 0 ? (eq_next && !eq_prev) : (eq_prev && !eq_next);
+                            }
+                            const unsigned long long mask = __ballot(f);
+                            const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+                            if (lane == 0)
+                                misc_s[MS_WAVES + wave] = __popcll(mask);
+                            __syncthreads();
+                            int off = 0, tot = 0;
+                            for (int w = 0; w < T / 64; ++w) {
+                                const int cw = misc_s[MS_WAVES + w];
+                                if (w < wave)
+                                    off += cw;
+                                tot += cw;
+                            }
+                            if (f && base + off + prefix < RCAP) {
+                                if (pass == 0)
+                                    rl_head[base + off + prefix] = i;
+                                else
+                                    rl_len[base + off + prefix] = i; // (the last position, for now)
+                            }
+                            base += tot;
+                            __syncthreads();
+                        }
+                        if (pass == 0)
+                            nh = base;
+                        else
+                            nt = base;
+                    }
+                    const int nruns = nh;
+                    (void)nt;
+                    if (nruns <= RCAP) {
+                        runs_listed = true;
+                        for (int q = tid; q < nruns; q += T)
+                            rl_len[q] = rl_len[q] - rl_head[q] + 1;
+                        __syncthreads();
+                        int qb = 0;               // runs in front of qb are done
+                        unsigned st_row = rng.s;  // the engine in front of run qb
+                        while (qb < nruns) {
+                            if (tid == 0) {
+                                int acc = 0;
+                                for (int q = qb; q < nruns; ++q) {
+                                    rl_base[q] = acc;
+                                    acc += rl_len[q] >> 1;
+                                }
+                                misc_s[WM_TAKE] = nruns;   // first run with a rejected draw
+                                misc_s[WM_FLAG] = acc;     // draws of the runs from qb on
+                            }
+                            __syncthreads();
+                            const int total_draws = misc_s[WM_FLAG];
+                            const bool table_ok = total_draws + 1 < WIDE_LCG_POW;
+                            // pass over all draws: is any rejected?
+                            if (table_ok) {
+                                for (int q = qb + wave; q < nruns; q += T / 64) {
+                                    const int L = rl_len[q], bq = rl_base[q];
+                                    const bool even = (L & 1) == 0;
+                                    bool rej = false;
+                                    for (int d = lane; d < (L >> 1); d += 64) {
+                                        unsigned urange;
+                                        if (even && d == 0)
+                                            urange = 1u;
+                                        else {
+                                            const unsigned i0 = even ? 2u * (unsigned)d : 2u * (unsigned)d + 1u;
+                                            urange = (i0 + 1u) * (i0 + 2u) - 1u;
+                                        }
+                                        const unsigned uerange = urange + 1u;
+                                        const unsigned scaling = 2147483645u / uerange;
+                                        const unsigned past = uerange * scaling;
+                                        const unsigned raw = lcg_jump(pb.lcg_pow, st_row, bq + d + 1) - 1u;
+                                        rej |= raw >= past;
+                                    }
+                                    if (__ballot(rej) != 0ull && lane == 0)
+                                        atomicMin(&misc_s[WM_TAKE], q);
+                                }
+                            } else if (tid == 0)
+                                misc_s[WM_TAKE] = qb;
+                            __syncthreads();
+                            const int first_rej = misc_s[WM_TAKE];
+                            // the runs in front of it, side by side: one wave per run of up to 512
+                            const bool room = (T / 64) * 2 * 512 * 4 <= ring_bytes;
+                            if (room) {
+                                int* wsc = (int*)ring_s + wave * (2 * 512); // ids, partners
+                                for (int q = qb + wave; q < first_rej; q += T / 64) {
+                                    const int L = rl_len[q];
+                                    if (L > 512)
+                                        continue;
+                                    const int head = rl_head[q], bq = rl_base[q];
+                                    const bool even = (L & 1) == 0;
+                                    int* ids_w = wsc;
+                                    int* jt_w = wsc + 512;
+                                    for (int i = lane; i < L; i += 64) {
+                                        ids_w[i] = bid[head + i];
+                                        int jv = 0;
+                                        if (i >= 1) {
+                                            unsigned urange;
+                                            int d, half = 0;
+                                            unsigned b1 = 2;
+                                            if (even && i == 1) {
+                                                d = 0;
+                                                urange = 1u;
+                                            } else {
+                                                const int i0 = even ? (i & ~1) : (((i - 1) & ~1) + 1);
+                                                d = even ? (i >> 1) : ((i - 1) >> 1);
+                                                half = i - i0;
+                                                b1 = (unsigned)i0 + 2u;
+                                                urange = ((unsigned)i0 + 1u) * b1 - 1u;
+                                            }
+                                            const unsigned uerange = urange + 1u;
+                                            const unsigned scaling = 2147483645u / uerange;
+                                            const unsigned raw = lcg_jump(pb.lcg_pow, st_row, bq + d + 1) - 1u;
+                                            const unsigned xv = raw / scaling;
+                                            jv = (even && i == 1) ? (int)xv
+                                                                  : (half == 0 ? (int)(xv / b1) : (int)(xv % b1));
+                                        }
+                                        jt_w[i] = jv;
+                                    }
+                                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (one wave: LDS in order)
+                                    for (int p0 = lane; p0 < L; p0 += 64) {
+                                        int pos = p0;
+                                        for (int i = L - 1; i >= 1; --i) {
+                                            const int j = jt_w[i];
+                                            pos = pos == i ? j : (pos == j ? i : pos);
+                                        }
+                                        bid[head + p0] = ids_w[pos];
+                                    }
+                                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                }
+                            }
+                            __syncthreads();
+                            // the longer runs in front of it, one after the other
+                            {
+                                int* ids_l = (int*)ring_s;
+                                const int cap_run = min(2048, ring_bytes / 12);
+                                int* jt_l = ids_l + cap_run;
+                                int* out_l = jt_l + cap_run;
+                                for (int q = qb; q < first_rej; ++q) {
+                                    const int L = rl_len[q];
+                                    if (room && L <= 512)
+                                        continue;
+                                    const int head = rl_head[q];
+                                    unsigned stq = lcg_jump(pb.lcg_pow, st_row, rl_base[q]);
+                                    if (L <= cap_run) {
+                                        for (int i = tid; i < L; i += T)
+                                            ids_l[i] = bid[head + i];
+                                        __syncthreads();
+                                        // (no draw of this run is rejected: checked above)
+                                        wide_run_shuffle(ids_l, L, &stq, pb.lcg_pow, jt_l, out_l, misc_s + WM_FLAG);
+                                        for (int i = tid; i < L; i += T)
+                                            bid[head + i] = ids_l[i];
+                                        __syncthreads();
+                                    } else {
+                                        if (tid == 0) {
+                                            MinStd e;
+                                            e.s = stq;
+                                            e.shuffle(bid + head, (unsigned)L);
+                                        }
+                                        __syncthreads();
+                                    }
+                                }
+                            }
+                            if (first_rej >= nruns) {
+                                st_row = lcg_jump(pb.lcg_pow, st_row, total_draws);
+                                qb = nruns;
+                            } else {
+                                // the run with the rejected draw: by one thread, in LDS when it fits
+                                const int L = rl_len[first_rej], head = rl_head[first_rej];
+                                const unsigned stq = lcg_jump(pb.lcg_pow, st_row, rl_base[first_rej]);
+                                int* ids_l = (int*)ring_s;
+                                const bool in_lds = L * 4 <= ring_bytes;
+                                if (in_lds)
+                                    for (int i = tid; i < L; i += T)
+                                        ids_l[i] = bid[head + i];
+                                __syncthreads();
+                                if (tid == 0) {
+                                    MinStd e;
+                                    e.s = stq;
+                                    if (in_lds)
+                                        e.shuffle(ids_l, (unsigned)L);
+                                    else
+                                        e.shuffle(bid + head, (unsigned)L);
+                                    misc_s[MS_RNG] = (int)e.s;
+                                }
+                                __syncthreads();
+                                if (in_lds)
+                                    for (int i = tid; i < L; i += T)
+                                        bid[head + i] = ids_l[i];
+                                st_row = (unsigned)misc_s[MS_RNG];
+                                qb = first_rej + 1;
+                                __syncthreads();
+                            }
+                        }
+                        serial_head = r;
+                        serial_state = st_row;
+                    }
+                    __syncthreads();
+                    if (tid == 0)
+                        ring_s[wp.ring] = 0; // (the scratch took the padding entry of the window)
+                    __syncthreads();
+                }
                 auto val_of = [&](int idx) -> Float {
                     return (Float)__longlong_as_double((long long)__hip_atomic_load(
                       &vbuf[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1421,9 +1823,10 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 if (tid == 0) {
                     if (grp == 0)
                         alg_bytes += pb.row_bytes[k];
-                    if (misc_s[MS_TIE]) {
-                        int b0 = 0;
-                        for (int i = 1; i <= r; ++i) {
+                    if (misc_s[MS_TIE]) { // what is left of the tied runs (all of them when the
+                        rng.s = runs_listed ? serial_state : rng.s; // runs were not listed), serially
+                        int b0 = runs_listed ? serial_head : 0;
+                        for (int i = b0 + 1; i <= r; ++i) {
                             if (i == r || bkey[i] != bkey[b0]) {
                                 rng.shuffle(bid + b0, (unsigned)(i - b0));
                                 b0 = i;
