@@ -50,6 +50,24 @@ def test_wide_kernel_long_tied_rows(oracle, bxh, monkeypatch):
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=3, push_at=(2,), expect_form=104)
 
 
+@pytest.mark.parametrize("ncost", [2, 6, 40], ids=["runs-of-1500", "runs-of-500", "runs-of-75"])
+def test_wide_kernel_long_rows_tied_runs_side_by_side(oracle, bxh, ncost, monkeypatch):
+    """40 rows of 3000 elements whose integer costs take `ncost` values, among
+    4200 rows (so that the pi window -- the LDS scratch of the long-row path -- is
+    64 KB as at the XL shape): the tied runs of a row are shuffled side by side
+    from jumps of the engine, a wave per run (<= 512), all threads (<= 2048) or
+    one thread (longer), and with runs this long some draw is rejected in almost
+    every row (the scheme restarts behind that run)."""
+    monkeypatch.setenv("BXH_GROUPS", "w4")
+    rs = np.random.RandomState(400 + ncost)
+    n, nlong, m = 12000, 40, 4200
+    rows = [np.sort(rs.choice(n, size=3000, replace=False)) for _ in range(nlong)]
+    rows += [np.array([rs.randint(n)]) for _ in range(m - nlong)]
+    costs = rs.randint(1, ncost + 1, n).astype(float)
+    inst = _custom(rows, n, [1] * m, [2 ** 30] * m, costs, kind=1)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=3, push_at=(2,), expect_form=104)
+
+
 def test_wide_kernel_is_chosen_for_long_columns(oracle, bxh, monkeypatch):
     """Columns of ~300 entries: bxh_create picks the wide kernel by itself."""
     monkeypatch.delenv("BXH_GROUPS", raising=False)
