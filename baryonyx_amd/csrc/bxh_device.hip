@@ -104,6 +104,10 @@ struct bxh_handle_s
     // 1: the instance's list R is known to be empty (a sweep over it is a no-op);
     // 0: unknown or not empty.  Maintained by the calls that read `remaining` back.
     std::vector<unsigned char> known_empty;
+    // device-resident population (bxh_pop_*, bxh_reinit)
+    DevBuf<unsigned> pop;     // [slots + 1][2 * nwords]
+    int pop_slots = -1;
+    DevBuf<bxh::ReinitJob> jobs_d;
     std::vector<unsigned char> skipped; // the instance's last sweep was such a no-op: nothing was launched
     DevBuf<double> stage_d;    // bxh_set_P / bxh_get_P of a device-built handle: one chunk
     unsigned epoch = 0;        // sweep launches so far (tags of the row exchange)
@@ -1862,6 +1866,110 @@ bxh_set_rng_all(bxh_handle h, const uint32_t* state)
     // (the engine state is a field of the per-instance status block)
     HIP_TRY(hipMemcpy2D(&h->status.p[0].rng, sizeof(bxh::DevStatus), state, sizeof(uint32_t),
                         sizeof(uint32_t), static_cast<size_t>(h->batch), hipMemcpyHostToDevice));
+    return BXH_OK;
+}
+
+int
+bxh_pop_create(bxh_handle h, int slots)
+{
+    if (!h || slots <= 0)
+        return fail(BXH_ERR_INVALID, "bxh_pop_create: null handle or no slots");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->pop.alloc((static_cast<size_t>(slots) + 2) * 2 * h->nwords));
+    h->pop_slots = slots;
+    return BXH_OK;
+}
+
+static int
+check_slot(bxh_handle h, int slot)
+{
+    if (!h)
+        return fail(BXH_ERR_INVALID, "null handle");
+    if (h->pop_slots < 0)
+        return fail(BXH_ERR_INVALID, "no population: call bxh_pop_create first");
+    if (slot < 0 || slot > h->pop_slots + 1)
+        return fail(BXH_ERR_INVALID, "population slot out of range");
+    return BXH_OK;
+}
+
+int
+bxh_pop_set(bxh_handle h, int slot, const uint64_t* words)
+{
+    if (int rc = check_slot(h, slot))
+        return rc;
+    if (!words)
+        return fail(BXH_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->pop.p + static_cast<size_t>(slot) * 2 * h->nwords, words,
+                           static_cast<size_t>(h->nwords) * 8, hipMemcpyHostToDevice, h->stream));
+    return BXH_OK;
+}
+
+int
+bxh_pop_get(bxh_handle h, int slot, uint64_t* words)
+{
+    if (int rc = check_slot(h, slot))
+        return rc;
+    if (!words)
+        return fail(BXH_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(words, h->pop.p + static_cast<size_t>(slot) * 2 * h->nwords,
+                      static_cast<size_t>(h->nwords) * 8, hipMemcpyDeviceToHost));
+    return BXH_OK;
+}
+
+int
+bxh_pop_store(bxh_handle h, int slot, int inst)
+{
+    if (int rc = check_slot(h, slot))
+        return rc;
+    if (int rc = check_inst(h, inst))
+        return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->pop.p + static_cast<size_t>(slot) * 2 * h->nwords,
+                           h->x.p + static_cast<size_t>(inst) * 2 * h->nwords,
+                           static_cast<size_t>(h->nwords) * 8, hipMemcpyDeviceToDevice, h->stream));
+    return BXH_OK;
+}
+
+int
+bxh_reinit(bxh_handle h, int njobs, const bxh_reinit_job* jobs)
+{
+    if (!h || (njobs > 0 && !jobs))
+        return fail(BXH_ERR_INVALID, "null argument");
+    if (njobs <= 0)
+        return BXH_OK;
+    static_assert(sizeof(bxh_reinit_job) == sizeof(bxh::ReinitJob), "job layouts differ");
+    for (int q = 0; q != njobs; ++q) {
+        const bxh_reinit_job& jb = jobs[q];
+        if (jb.inst < 0 || jb.inst >= h->batch)
+            return fail(BXH_ERR_INVALID, "bxh_reinit: instance out of range");
+        if (jb.cross < 0 || jb.cross > 1)
+            return fail(BXH_ERR_INVALID, "bxh_reinit: unknown crossover kind");
+        if (jb.cross && (h->pop_slots < 0 || jb.first < 0 || jb.first > h->pop_slots + 1 ||
+                         jb.second < 0 || jb.second > h->pop_slots + 1))
+            return fail(BXH_ERR_INVALID, "bxh_reinit: population slot out of range");
+        const uint32_t s0 = jb.cross ? jb.rng_cross : jb.rng_mut;
+        if (s0 == 0 || s0 >= 2147483647u || jb.rng_mut == 0 || jb.rng_mut >= 2147483647u)
+            return fail(BXH_ERR_INVALID, "minstd_rand0 state must be in [1, 2^31-2]");
+        if (jb.mutate && !(jb.var_p > 0.0 && jb.var_p < 1.0 && jb.val_p >= 0.0 && jb.val_p <= 1.0))
+            return fail(BXH_ERR_INVALID, "bxh_reinit: mutation probabilities out of range");
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->jobs_d.count < static_cast<size_t>(njobs)) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(h->jobs_d.alloc(static_cast<size_t>(std::max(njobs, h->batch))));
+    }
+    HIP_TRY(hipMemcpyAsync(h->jobs_d.p, jobs, static_cast<size_t>(njobs) * sizeof(bxh_reinit_job),
+                           hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(bxh::reinit_kernel, dim3(njobs), dim3(64), 0, h->stream, h->dp, h->ds, h->jobs_d.p,
+                       h->pop.p);
+    HIP_TRY(hipGetLastError());
+    h->known_empty.resize(static_cast<size_t>(h->batch), 0);
+    for (int q = 0; q != njobs; ++q)
+        h->known_empty[static_cast<size_t>(jobs[q].inst)] = 0;
     return BXH_OK;
 }
 

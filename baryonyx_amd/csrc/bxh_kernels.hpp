@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bxh_rng.hpp"
+
 namespace bxh {
 
 struct DevProblem
@@ -4245,6 +4247,87 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         s.alg_bytes += alg_bytes;
         st.status[inst] = s;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Restart of an instance with the population on the device (bxh_reinit,
+// include/bxh.h): crossover (lib/src/itm-optimizer-common.hpp:359-371) and
+// mutation (:494-526) of `best_solution_recorder::reinit` (:528-554).  One
+// workgroup per job.  The engine is sequential, so thread 0 draws; the mutation
+// loop spends two draws per variable and two more where the first Bernoulli
+// hits (one variable in 10^4 by default): the lanes look for the next hit with
+// jumps of the engine, thread 0 handles it.
+struct ReinitJob // == bxh_reinit_job
+{
+    int inst, cross, first, second;
+    unsigned rng_cross;
+    int mutate;
+    unsigned rng_mut, pad_;
+    double var_p, val_p;
+};
+
+__global__ __launch_bounds__(64) void
+reinit_kernel(DevProblem pb, DevState st, const ReinitJob* jobs, const unsigned* pop)
+{
+    __shared__ int next_hit;
+    const ReinitJob jb = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int nw32 = 2 * pb.nwords;
+    unsigned* xg = st.x + (size_t)jb.inst * nw32;
+    unsigned state = jb.rng_mut;
+    if (jb.cross) {
+        const unsigned* x1 = pop + (size_t)jb.first * nw32;
+        const unsigned* x2 = pop + (size_t)jb.second * nw32;
+        // the masks: sequential draws (three per block, more when one is rejected)
+        if (lane == 0) {
+            Lcg g{ jb.rng_cross };
+            for (int i = 0; i < pb.nwords; ++i) {
+                const unsigned long long mask = lcg_uniform_u64(g, ~0ull);
+                const unsigned long long a = ((unsigned long long)x1[2 * i + 1] << 32) | x1[2 * i];
+                const unsigned long long b = ((unsigned long long)x2[2 * i + 1] << 32) | x2[2 * i];
+                const unsigned long long v = ((a ^ b) & mask) ^ a;
+                xg[2 * i] = (unsigned)v;
+                xg[2 * i + 1] = (unsigned)(v >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    if (jb.mutate) {
+        // variables [from, n): every lane tests a stretch of them at the draw the
+        // variable would get if none before it in [from, n) hit
+        int from = 0;
+        const int CH = 1024; // jumps of at most 2 * CH draws (lcg_pow holds 32770 powers)
+        while (from < pb.n) {
+            const int upto = min(pb.n, from + CH);
+            if (lane == 0)
+                next_hit = upto;
+            __syncthreads();
+            for (int i = from + lane; i < upto; i += 64) {
+                Lcg g{ lcg_jump(pb.lcg_pow, state, 2 * (i - from)) };
+                if (lcg_bernoulli(g, jb.var_p))
+                    atomicMin(&next_hit, i);
+            }
+            __syncthreads();
+            const int hit = next_hit;
+            state = lcg_jump(pb.lcg_pow, state, 2 * (hit - from));
+            if (hit < upto) {
+                Lcg g{ state };
+                (void)lcg_bernoulli(g, jb.var_p); // the hit itself
+                const bool v = lcg_bernoulli(g, jb.val_p);
+                state = g.s;
+                if (lane == 0) {
+                    const unsigned bit = 1u << (hit & 31);
+                    const unsigned w = xg[hit >> 5];
+                    xg[hit >> 5] = v ? (w | bit) : (w & ~bit);
+                }
+                from = hit + 1;
+            } else
+                from = upto;
+            __syncthreads();
+        }
+    }
+    if (lane == 0)
+        st.status[jb.inst].rng = state;
 }
 
 } // namespace bxh

@@ -22,6 +22,12 @@ struct bxc_params
     int device;
     long long sweep_budget;
     int preprocessor; // solver_parameters::preprocessor_options: 0 none, 1 all
+    int pad_;
+    // the evolutionary layer of optimize() (core:216-229)
+    double init_crossover_bastert_insertion, init_crossover_solution_selection_mean,
+      init_crossover_solution_selection_stddev, init_mutation_variable_mean,
+      init_mutation_variable_stddev, init_mutation_value_mean, init_mutation_value_stddev,
+      init_kappa_improve_start, init_kappa_improve_increase, init_kappa_improve_stop;
 };
 
 struct bxc_problem_info
@@ -68,6 +74,16 @@ bxc_default_params(bxc_params* p)
     p->cost_norm = static_cast<int>(d.cost_norm);
     p->pre_order = static_cast<int>(d.pre_order);
     p->preprocessor = static_cast<int>(d.preprocessor);
+    p->init_crossover_bastert_insertion = d.init_crossover_bastert_insertion;
+    p->init_crossover_solution_selection_mean = d.init_crossover_solution_selection_mean;
+    p->init_crossover_solution_selection_stddev = d.init_crossover_solution_selection_stddev;
+    p->init_mutation_variable_mean = d.init_mutation_variable_mean;
+    p->init_mutation_variable_stddev = d.init_mutation_variable_stddev;
+    p->init_mutation_value_mean = d.init_mutation_value_mean;
+    p->init_mutation_value_stddev = d.init_mutation_value_stddev;
+    p->init_kappa_improve_start = d.init_kappa_improve_start;
+    p->init_kappa_improve_increase = d.init_kappa_improve_increase;
+    p->init_kappa_improve_stop = d.init_kappa_improve_stop;
 }
 
 static context_ptr
@@ -98,6 +114,16 @@ make_ctx(const bxc_params* p)
     q.cost_norm = static_cast<solver_parameters::cost_norm_type>(p->cost_norm);
     q.pre_order = static_cast<solver_parameters::pre_constraint_order>(p->pre_order);
     q.preprocessor = static_cast<solver_parameters::preprocessor_options>(p->preprocessor);
+    q.init_crossover_bastert_insertion = p->init_crossover_bastert_insertion;
+    q.init_crossover_solution_selection_mean = p->init_crossover_solution_selection_mean;
+    q.init_crossover_solution_selection_stddev = p->init_crossover_solution_selection_stddev;
+    q.init_mutation_variable_mean = p->init_mutation_variable_mean;
+    q.init_mutation_variable_stddev = p->init_mutation_variable_stddev;
+    q.init_mutation_value_mean = p->init_mutation_value_mean;
+    q.init_mutation_value_stddev = p->init_mutation_value_stddev;
+    q.init_kappa_improve_start = p->init_kappa_improve_start;
+    q.init_kappa_improve_increase = p->init_kappa_improve_increase;
+    q.init_kappa_improve_stop = p->init_kappa_improve_stop;
     context_set_solver_parameters(ctx, q);
     context_set_parameters(ctx, "device", std::to_string(p->device));
     if (const char* dl = std::getenv("BXC_DEVICES")) // e.g. "0,1,2,3": optimize() over several devices

@@ -18,6 +18,7 @@
 #include "../../include/bxh.h"
 
 #include <algorithm>
+#include <functional>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -457,6 +458,15 @@ struct device_batch
     void get_x_all(std::uint64_t* words) { check(bxh_get_x_all(h, words)); }
     void set_x_all(const std::uint64_t* words) { check(bxh_set_x_all(h, words)); }
     void set_rng_all(const std::uint32_t* states) { check(bxh_set_rng_all(h, states)); }
+    // the population of optimize() on the device (bxh.h: bxh_pop_*, bxh_reinit)
+    void pop_create(int slots) { check(bxh_pop_create(h, slots)); }
+    void pop_set(int slot, const bit_array& x) { check(bxh_pop_set(h, slot, x.w.data())); }
+    void pop_store(int slot, int i) { check(bxh_pop_store(h, slot, i)); }
+    void reinit(const std::vector<bxh_reinit_job>& jobs)
+    {
+        check(bxh_reinit(h, static_cast<int>(jobs.size()), jobs.data()));
+    }
+    void pop_get(int slot, bit_array& x) { check(bxh_pop_get(h, slot, x.w.data())); }
 };
 
 // The worker pool of optimize() over several devices: worker b lives on device
@@ -553,6 +563,46 @@ struct device_pool
         rmirror[d][static_cast<size_t>(at[b].i)] = engine_state(e);
         rng_dirty[d] = 1;
     }
+    // ---- the population on the devices (every device holds a copy) ----------
+    std::vector<std::vector<bxh_reinit_job>> pending; // restarts not yet launched, per device
+    std::vector<char> stale_x;                        // the mirror of x is behind the device
+    void pop_create(int slots)
+    {
+        pending.assign(dev.size(), {});
+        stale_x.assign(dev.size(), 0);
+        for (auto& d : dev)
+            d->pop_create(slots);
+    }
+    void pop_set_all(int slot, const bit_array& x)
+    {
+        for (auto& d : dev)
+            d->pop_set(slot, x);
+    }
+    // slot <- x of worker b: a device copy where the worker lives, an upload elsewhere
+    void pop_from_worker(int slot, int b, const bit_array& x)
+    {
+        const int db = dev_of(b);
+        for (int d = 0; d != static_cast<int>(dev.size()); ++d) {
+            if (d == db)
+                dev[d]->pop_store(slot, at[b].i);
+            else
+                dev[d]->pop_set(slot, x);
+        }
+    }
+    void add_job(int b, bxh_reinit_job jb)
+    {
+        jb.inst = at[b].i;
+        pending[static_cast<size_t>(dev_of(b))].push_back(jb);
+    }
+    void launch_jobs()
+    {
+        for (size_t d = 0; d != dev.size(); ++d)
+            if (!pending.empty() && !pending[d].empty()) {
+                dev[d]->reinit(pending[d]);
+                pending[d].clear();
+                stale_x[d] = 1;
+            }
+    }
     // what the host changed since the last sweep goes to the devices
     void flush()
     {
@@ -607,8 +657,11 @@ struct device_pool
                 bool moved = false; // (a sweep over empty lists is not even launched)
                 for (int i = 0; i != dev[d]->batch; ++i)
                     moved = moved || dev[d]->status[i].rows_in_sweep != 0;
-                if (moved)
+                if (moved || (!stale_x.empty() && stale_x[d])) {
                     dev[d]->get_x_all(xmirror[d].data());
+                    if (!stale_x.empty())
+                        stale_x[d] = 0;
+                }
                 launched[d] = 0;
             }
             for (int i = 0; i != dev[d]->batch; ++i)
@@ -871,6 +924,10 @@ struct recorder
     std::vector<int> indices;
     std::vector<raw_result> data;
     bit_array bastert, random;
+    // population on the devices (f3): told of every bit vector that enters a slot --
+    // (slot, worker whose x it is or -1, the vector); slots `size` and `size + 1`
+    // are the Bastert vector and the scratch vector of crossover()
+    std::function<void(int, int, const bit_array&)> on_store;
     const cost_type<Float>& costs;
     double cost_constant;
     int size;
@@ -987,6 +1044,88 @@ struct recorder
         }
     }
 
+    // ---- the same restart as a job for the device (bxh_reinit): every decision
+    // and every draw of reinit() that is not a bit operation on a whole vector is
+    // taken here, in the same order; the masks of cross() and the mutation loop
+    // run on the device from the engine states noted in the job ----------------
+    void cross_job(local_context& ctx, bxh_reinit_job& jb, int first_slot, int second_slot, int blocks)
+    {
+        jb.cross = 1;
+        jb.first = first_slot;
+        jb.second = second_slot;
+        jb.rng_cross = engine_state(ctx.rng);
+        for (int i = 0; i != blocks; ++i)
+            (void)ctx.crossover_dist(ctx.rng); // (the device forms the masks; here they only advance the engine)
+    }
+
+    void crossover_job(local_context& ctx, bxh_reinit_job& jb, int blocks) // :373-421
+    {
+        if (ctx.crossover_bastert_insertion(ctx.rng)) {
+            const int first = indices[choose_a_solution(ctx)];
+            std::bernoulli_distribution b(0.5);
+            if (b(ctx.rng)) {
+                if (b(ctx.rng))
+                    cross_job(ctx, jb, first, size, blocks);
+                else {
+                    data[first].x = bastert;
+                    if (on_store)
+                        on_store(first, -1, bastert);
+                }
+            } else {
+                init_with_random(random, ctx.rng, 0.5);
+                if (b(ctx.rng)) {
+                    if (on_store)
+                        on_store(size + 1, -1, random);
+                    cross_job(ctx, jb, first, size + 1, blocks);
+                } else {
+                    data[first].x = random;
+                    if (on_store)
+                        on_store(first, -1, random);
+                }
+            }
+        } else {
+            const int first = indices[choose_a_solution(ctx)];
+            int second = indices[choose_a_solution(ctx)];
+            while (first == second)
+                second = indices[choose_a_solution(ctx)];
+            cross_job(ctx, jb, first, second, blocks);
+        }
+    }
+
+    void mutation_job(local_context& ctx, bxh_reinit_job& jb) // :494-526
+    {
+        jb.mutate = 0;
+        if (!(ctx.value_p_dist.mean() == 0.0 && ctx.value_p_dist.stddev() == 0.0)) {
+            double val_p, var_p;
+            do
+                var_p = ctx.variable_p_dist(ctx.rng);
+            while (var_p <= 0.0 || var_p >= 1.0);
+            do
+                val_p = ctx.value_p_dist(ctx.rng);
+            while (val_p < 0.0 || val_p > 1.0);
+            jb.mutate = 1;
+            jb.var_p = var_p;
+            jb.val_p = val_p;
+        }
+        jb.rng_mut = engine_state(ctx.rng);
+    }
+
+    double reinit_job(local_context& ctx, int worker, const solver_parameters& p, bxh_reinit_job& jb,
+                      int blocks) // :528-554
+    {
+        jb = bxh_reinit_job{};
+        double kappa = p.kappa_min;
+        if (kappa_append[worker] < p.init_kappa_improve_stop) {
+            kappa_append[worker] += p.init_kappa_improve_increase;
+            kappa = p.kappa_min + (p.kappa_max - p.kappa_min) * kappa_append[worker];
+        } else {
+            kappa_append[worker] = p.init_kappa_improve_start;
+            crossover_job(ctx, jb, blocks);
+        }
+        mutation_job(ctx, jb);
+        return kappa;
+    }
+
     void mutation(local_context& ctx, bit_array& x) // :494-526
     {
         if (ctx.value_p_dist.mean() == 0.0 && ctx.value_p_dist.stddev() == 0.0)
@@ -1018,11 +1157,14 @@ struct recorder
         return kappa;
     }
 
+    int store_worker = -1; // the worker whose device x the vector given to replace() is (or -1)
     void replace(local_context& ctx, const bit_array& x, std::size_t hash, double value,
                  long loop, int remaining)
     {
         const int id = indices[ctx.bad_solution_choose(ctx.rng)];
         data[id].x = x;
+        if (on_store)
+            on_store(id, store_worker, x);
         data[id].value = value;
         data[id].duration =
           std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
@@ -1168,6 +1310,28 @@ optimize_problem(const context& ctx, const problem& pb)
     for (auto& w : wk)
         w.x = bit_array(variables);
 
+    // f3: the population also lives on the devices, a restart builds the worker's x
+    // there (bxh_reinit) from the parents' device copies: no bit vector goes to a
+    // device at a restart.  BXC_HOST_REINIT=1 keeps the round-1 way (x built on the
+    // host, the batch of x uploaded), for A/B runs and tests.
+    const bool device_population = std::getenv("BXC_HOST_REINIT") == nullptr;
+    if (device_population) {
+        slv.pop_create(best_recorder.size);
+        for (int id = 0; id != best_recorder.size; ++id)
+            slv.pop_set_all(id, best_recorder.data[static_cast<size_t>(id)].x);
+        slv.pop_set_all(best_recorder.size, best_recorder.bastert);
+        best_recorder.on_store = [&](int slot, int worker, const bit_array& x) {
+            slv.launch_jobs(); // (restarts noted so far read the slot as it was)
+            if (worker >= 0)
+                slv.pop_from_worker(slot, worker, x);
+            else
+                slv.pop_set_all(slot, x);
+        };
+    }
+    const int blocks = wk[0].x.block_size();
+    if (device_population && blocks != slv.dev[0]->nwords)
+        throw std::runtime_error("bit_array blocks != device words");
+
     const auto start = std::chrono::steady_clock::now();
     auto elapsed = [&]() {
         return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
@@ -1201,6 +1365,8 @@ optimize_problem(const context& ctx, const problem& pb)
             break;
 
         // -- restarts (reinit + compute.init), per worker in id order --------
+        if (device_population)
+            slv.flush(); // (engine states the bookkeeping changed: in front of the jobs' own)
         bool any_init = false;
         std::fill(init_mask.begin(), init_mask.end(), std::uint8_t{ 0 });
         for (int b = 0; b != workers; ++b) {
@@ -1210,16 +1376,24 @@ optimize_problem(const context& ctx, const problem& pb)
             init_mask[static_cast<size_t>(b)] = 1;
             ++w.calls;
             w.value_ok = false;
-            w.kappa_start = static_cast<Float>(best_recorder.reinit(lctx[b], b, p, w.x));
+            if (device_population) {
+                bxh_reinit_job jb;
+                w.kappa_start = static_cast<Float>(best_recorder.reinit_job(lctx[b], b, p, jb, blocks));
+                slv.add_job(b, jb); // x and the engine of the worker: left on the device by the job
+            } else {
+                w.kappa_start = static_cast<Float>(best_recorder.reinit(lctx[b], b, p, w.x));
+                slv.set_x(b, w.x);
+                slv.set_rng(b, lctx[b].rng);
+            }
             w.kappa = w.kappa_start;
             w.best_remaining = INT_MAX;
             w.i = 0;
             w.push = 0;
             w.phase = PH_MAIN;
-            slv.set_x(b, w.x);
-            slv.set_rng(b, lctx[b].rng);
             any_init = true;
         }
+        if (device_population)
+            slv.launch_jobs();
         if (any_init)
             slv.order_init(order, &init_mask); // compute.init of the restarted workers only
 
@@ -1260,7 +1434,9 @@ optimize_problem(const context& ctx, const problem& pb)
                     w.value = cost.results(w.x, cost_constant);
                     w.value_ok = true;
                 }
+                best_recorder.store_worker = b; // (w.x is the worker's x on its device)
                 best_recorder.try_update(lctx[b], w.x, w.value, loop);
+                best_recorder.store_worker = -1;
             };
             switch (w.phase) {
             case PH_MAIN: // :668-700
@@ -1277,7 +1453,9 @@ optimize_problem(const context& ctx, const problem& pb)
                 ++w.i;
                 if (w.kappa > kappa_max || w.i == p.limit) {
                     slv.get_x(b, w.x);
+                    best_recorder.store_worker = b;
                     best_recorder.try_advance(lctx[b], w.x, w.best_remaining, p.limit);
+                    best_recorder.store_worker = -1;
                     w.phase = PH_REINIT;
                 }
                 break;
@@ -1321,6 +1499,17 @@ optimize_problem(const context& ctx, const problem& pb)
         }
     }
 
+    // diagnostic (tests): every device's copy of the population == the host's
+    if (device_population && std::getenv("BXC_CHECK_POP")) {
+        bit_array got(variables);
+        for (auto& d : slv.dev)
+            for (int id = 0; id != best_recorder.size; ++id) {
+                d->pop_get(id, got);
+                if (got.w != best_recorder.data[static_cast<size_t>(id)].x.w)
+                    throw std::runtime_error("device population differs from the host's in slot " +
+                                             std::to_string(id));
+            }
+    }
     if (ctx.trace) {
         optimize_trace& t = *ctx.trace;
         t.rounds = sweeps;

@@ -23,7 +23,12 @@ class Params(C.Structure):
         ("pushes_limit", C.c_int), ("pushing_iteration_limit", C.c_int),
         ("init_population_size", C.c_int), ("order", C.c_int), ("float_type", C.c_int),
         ("init_policy", C.c_int), ("cost_norm", C.c_int), ("pre_order", C.c_int),
-        ("device", C.c_int), ("sweep_budget", C.c_longlong), ("preprocessor", C.c_int)]
+        ("device", C.c_int), ("sweep_budget", C.c_longlong), ("preprocessor", C.c_int),
+        ("pad_", C.c_int)] + [(n, C.c_double) for n in (
+            "init_crossover_bastert_insertion init_crossover_solution_selection_mean "
+            "init_crossover_solution_selection_stddev init_mutation_variable_mean "
+            "init_mutation_variable_stddev init_mutation_value_mean init_mutation_value_stddev "
+            "init_kappa_improve_start init_kappa_improve_increase init_kappa_improve_stop").split()]
 
 
 class ProblemInfo(C.Structure):

@@ -186,6 +186,43 @@ int bxh_set_x_all(bxh_handle h, const uint64_t* words_batch);
  * its whole worker pool */
 int bxh_get_x_all(bxh_handle h, uint64_t* words_batch);
 int bxh_set_rng_all(bxh_handle h, const uint32_t* state_batch);
+
+/* The evolutionary layer of optimize() with the population on the device
+ * (`storage` / `best_solution_recorder`, lib/src/itm-optimizer-common.hpp:93-601):
+ * the bit vectors of the population live in device memory, a solution enters
+ * it by a device copy of its instance's x (bxh_pop_store), and a restart builds
+ * the instance's new x there -- block-wise crossover ((x1 ^ x2) & mask) ^ x1 with
+ * the masks drawn from the worker's engine (:359-371) and the mutation loop
+ * (:494-526: one Bernoulli draw per variable, a second where it hits) -- so
+ * that no bit vector crosses PCIe at a restart.  The host keeps what it
+ * decides: which solutions are crossed (choose_a_solution's normal draws) and
+ * the two mutation probabilities; it passes the engine state in front of the
+ * masks and in front of the mutation loop (the masks take a number of draws the
+ * host can count without forming them), the device leaves the state behind
+ * the loop in the instance's engine. */
+typedef struct bxh_reinit_job
+{
+    int32_t inst;       /* instance whose x is rebuilt */
+    int32_t cross;      /* 0: x stays; 1: crossover of slots first / second (the two extra slots,
+                           indices slots and slots + 1, hold what the host puts there: the Bastert
+                           vector, a random vector) */
+    int32_t first, second;
+    uint32_t rng_cross; /* engine state in front of the crossover's mask draws */
+    int32_t mutate;     /* 0 / 1 */
+    uint32_t rng_mut;   /* engine state in front of the mutation's draws (== behind the masks) */
+    uint32_t pad_;
+    double var_p, val_p; /* mutation: P(variable is redrawn), P(it becomes 1) */
+} bxh_reinit_job;
+/* `slots` vectors + two extra (indices `slots`, `slots + 1`) */
+int bxh_pop_create(bxh_handle h, int slots);
+int bxh_pop_set(bxh_handle h, int slot, const uint64_t* words);
+int bxh_pop_get(bxh_handle h, int slot, uint64_t* words);
+/* population[slot] <- x of instance `inst` (device copy, on the stream) */
+int bxh_pop_store(bxh_handle h, int slot, int inst);
+/* the jobs' crossovers and mutations, one workgroup per job, on the stream;
+ * afterwards x and the engine state of every job's instance are the new ones */
+int bxh_reinit(bxh_handle h, int njobs, const bxh_reinit_job* jobs);
+
 int bxh_set_pi(bxh_handle h, int inst, const double* pi_m);
 int bxh_get_pi(bxh_handle h, int inst, double* pi_m);
 int bxh_set_P(bxh_handle h, int inst, const double* P_nnz);

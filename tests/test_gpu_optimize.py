@@ -18,7 +18,11 @@ pytestmark = pytest.mark.gpu
 
 COMMON = ("theta delta kappa_min kappa_step kappa_max alpha pushing_k_factor "
           "pushing_objective_amplifier init_policy_random w limit seed pushes_limit "
-          "pushing_iteration_limit init_population_size order init_policy cost_norm").split()
+          "pushing_iteration_limit init_population_size order init_policy cost_norm "
+          "init_crossover_bastert_insertion init_crossover_solution_selection_mean "
+          "init_crossover_solution_selection_stddev init_mutation_variable_mean "
+          "init_mutation_variable_stddev init_mutation_value_mean init_mutation_value_stddev "
+          "init_kappa_improve_start init_kappa_improve_increase init_kappa_improve_stop").split()
 
 OPT_CASES = [
     # (name, maker, float_type, thread, rounds, params)
@@ -36,6 +40,20 @@ OPT_CASES = [
      dict(limit=50, w=5.0, init_population_size=12, pushes_limit=2, pushing_iteration_limit=5)),
     ("scp-l2-norm", lambda: synth.make_scp(60, 400, 0.06, "real", 13), 1, 4, 150,
      dict(limit=60, w=5.0, init_population_size=10, cost_norm=3)),
+    # every restart is a crossover (init_kappa_improve_stop = 0) followed by a mutation
+    # that redraws a few per cent of the variables: the restarts of the device-resident
+    # population (bxh_reinit: masks and the mutation loop drawn on the device)
+    ("crossover-every-restart", lambda: synth.make_scp(60, 400, 0.06, "int", 41), 1, 8, 300,
+     dict(limit=25, w=5.0, init_population_size=12, init_kappa_improve_stop=0.0,
+          init_mutation_variable_mean=0.02, init_mutation_variable_stddev=0.01)),
+    # ... mostly through the Bastert / random-vector branches of crossover()
+    # (itm-optimizer-common.hpp:377-407), which also overwrite population slots
+    ("crossover-insertions", lambda: synth.make_spp(40, 300, 0.06, "int", 42), 1, 6, 300,
+     dict(limit=20, w=5.0, init_population_size=10, init_kappa_improve_stop=0.0,
+          init_crossover_bastert_insertion=0.7, kappa_max=0.9)),
+    ("crossover-no-mutation-f32", lambda: synth.make_pm1(50, 250, 0.06, "real", 43), 0, 5, 250,
+     dict(limit=20, w=5.0, init_population_size=10, init_kappa_improve_stop=0.04,
+          init_mutation_value_mean=0.0, init_mutation_value_stddev=0.0)),
 ]
 
 
@@ -45,8 +63,18 @@ def both_params(oracle, **kw):
     return hp, okw
 
 
+@pytest.mark.parametrize("reinit", ["device", "host"])
 @pytest.mark.parametrize("case", OPT_CASES, ids=[c[0] for c in OPT_CASES])
-def test_optimize_matches_oracle(oracle, tmp_path, case):
+def test_optimize_matches_oracle(oracle, tmp_path, case, reinit, monkeypatch):
+    """`device`: the population lives on the device and a restart's crossover /
+    mutation run there (bxh_reinit; at the end the device's copy of every slot is
+    compared with the host's, BXC_CHECK_POP); `host`: x is built on the host and
+    uploaded (BXC_HOST_REINIT).  Both must be the oracle's run."""
+    monkeypatch.setenv("BXC_CHECK_POP", "1")
+    if reinit == "host":
+        monkeypatch.setenv("BXC_HOST_REINIT", "1")
+    else:
+        monkeypatch.delenv("BXC_HOST_REINIT", raising=False)
     name, maker, float_type, thread, rounds, params = case
     path = str(tmp_path / "p.lp")
     synth.write_lp(maker(), path)
