@@ -30,7 +30,7 @@ BXH_ERR_DEVICE = -4
 # every symbol include/bxh.h declares (tests check the library exports them)
 SYMBOLS = [
     "bxh_last_error", "bxh_create", "bxh_create_device", "bxh_destroy", "bxh_set_stream", "bxh_batch",
-    "bxh_nwords", "bxh_rmax", "bxh_kernel_form", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_get_x_all", "bxh_set_rng_all", "bxh_pop_create", "bxh_pop_set", "bxh_pop_get", "bxh_pop_store", "bxh_reinit", "bxh_set_pi", "bxh_get_pi",
+    "bxh_nwords", "bxh_rmax", "bxh_kernel_form", "bxh_sweep_includes_scan", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_get_x_all", "bxh_set_rng_all", "bxh_pop_create", "bxh_pop_set", "bxh_pop_get", "bxh_pop_store", "bxh_reinit", "bxh_set_pi", "bxh_get_pi",
     "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset", "bxh_reset_all",
     "bxh_order_create", "bxh_order_init", "bxh_order_init_masked", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
     "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time",
@@ -257,6 +257,7 @@ class DeviceBatch:
         self.nwords = self.L.bxh_nwords(self.h)
         self.rmax = self.L.bxh_rmax(self.h)
         self.kernel_form = self.L.bxh_kernel_form(self.h)
+        self.sweep_includes_scan = self.L.bxh_sweep_includes_scan(self.h) != 0
         self._status = np.zeros(self.batch, STATUS_DTYPE)
 
     def close(self):

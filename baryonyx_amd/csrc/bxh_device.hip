@@ -65,7 +65,15 @@ struct DevBuf
             return e;
         static const bool poison = std::getenv("BXH_POISON") != nullptr;
         static const bool raw = std::getenv("BXH_NO_ZERO") != nullptr; // (diagnostic)
-        return raw ? hipSuccess : hipMemset(p, poison ? 0xA5 : 0, bytes);
+        if (raw)
+            return hipSuccess;
+        // (hipMemset on device memory is asynchronous, on the null stream; the
+        // handle's work runs on a non-blocking stream of its own, which does not
+        // wait for it: the fill must be over before anything else touches the buffer)
+        e = hipMemset(p, poison ? 0xA5 : 0, bytes);
+        if (e != hipSuccess)
+            return e;
+        return hipStreamSynchronize(nullptr);
     }
     hipError_t upload(const std::vector<T>& v)
     {
@@ -105,6 +113,7 @@ struct bxh_handle_s
     // 0: unknown or not empty.  Maintained by the calls that read `remaining` back.
     std::vector<unsigned char> known_empty;
     // device-resident population (bxh_pop_*, bxh_reinit)
+    DevBuf<unsigned> xt;      // wide kernel: x transposed over the instances (batch <= 32)
     DevBuf<unsigned> pop;     // [slots + 1][2 * nwords]
     int pop_slots = -1;
     DevBuf<bxh::ReinitJob> jobs_d;
@@ -272,6 +281,28 @@ drain_events(bxh_handle h)
         ++h->kernel_launches;
     }
     h->events_used = 0;
+    return BXH_OK;
+}
+
+// compute_violated_constraints of the wide layout for all (active) instances:
+// x transposed, one pass over A, the ordered compaction per instance
+int
+launch_wide_scan(bxh_handle h, const unsigned char* dev_active)
+{
+    hipLaunchKernelGGL(bxh::wide_transpose_kernel, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->dp,
+                       h->ds, h->xt.p, h->batch);
+    HIP_TRY(hipGetLastError());
+    const int blocks = std::max(1, std::min(2048, (h->m + 7) / 8));
+    if (h->batch <= 16)
+        hipLaunchKernelGGL((bxh::wide_flags_all_kernel<16>), dim3(blocks), dim3(512), 0, h->stream, h->dp,
+                           h->wp, h->xt.p, dev_active, h->batch);
+    else
+        hipLaunchKernelGGL((bxh::wide_flags_all_kernel<32>), dim3(blocks), dim3(512), 0, h->stream, h->dp,
+                           h->wp, h->xt.p, dev_active, h->batch);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(bxh::wide_compact_kernel, dim3(h->batch), dim3(512), 0, h->stream, h->dp, h->ds,
+                       h->wp, dev_active);
+    HIP_TRY(hipGetLastError());
     return BXH_OK;
 }
 
@@ -1179,6 +1210,8 @@ bxh_create(const bxh_problem* pb,
         HIP_TRY(h->bkey.alloc(B * Gz * n2big));
         HIP_TRY(h->bid.alloc(B * Gz * n2big));
         HIP_TRY(h->vflag32.alloc(B * static_cast<size_t>(m)));
+        if (batch <= 32 && !std::getenv("BXH_WIDE_OWN_SCAN"))
+            HIP_TRY(h->xt.alloc(static_cast<size_t>(n)));
         bxh::WideParams& wp = h->wp;
         wp.G = wide_g;
         wp.chmax = wide_chmax;
@@ -1195,6 +1228,10 @@ bxh_create(const bxh_problem* pb,
         wp.bkey = h->bkey.p;
         wp.bid = h->bid.p;
         wp.vflag32 = h->vflag32.p;
+    wp.xt = h->xt.p;
+    wp.skip_scan = h->xt.p ? 1 : 0;
+        wp.xt = h->xt.p;
+        wp.skip_scan = h->xt.p ? 1 : 0;
         const int wl = static_cast<int>(h->lds_bytes);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, wl));
@@ -1671,6 +1708,8 @@ bxh_create_device(const bxh_problem* pb,
     HIP_TRY(h->bkey.alloc(B * Gz * n2big));
     HIP_TRY(h->bid.alloc(B * Gz * n2big));
     HIP_TRY(h->vflag32.alloc(B * static_cast<size_t>(m)));
+        if (batch <= 32 && !std::getenv("BXH_WIDE_OWN_SCAN"))
+            HIP_TRY(h->xt.alloc(static_cast<size_t>(n)));
     HIP_TRY(hipStreamSynchronize(s));
 
     bxh::WideParams& wp = h->wp;
@@ -1778,6 +1817,14 @@ int
 bxh_rmax(bxh_handle h)
 {
     return h ? h->rmax : BXH_ERR_INVALID;
+}
+
+int
+bxh_sweep_includes_scan(bxh_handle h)
+{
+    if (!h)
+        return BXH_ERR_INVALID;
+    return (h->version == 4 && h->wp.skip_scan) ? 0 : 1;
 }
 
 int
@@ -2169,15 +2216,20 @@ bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* r
         dev_active = h->active.p;
     }
     if (h->version == 4) { // x, pi beyond LDS: flags from global memory, then the compaction
-        int parts = 1;
-        while (h->batch * parts * 2 <= 1024 && h->m / (parts * 2) >= 8)
-            parts *= 2;
-        hipLaunchKernelGGL(bxh::wide_flags_kernel, dim3(h->batch * parts), dim3(512), 0, h->stream,
-                           h->dp, h->ds, h->wp, dev_active, parts);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bxh::wide_compact_kernel, dim3(h->batch), dim3(512), 0, h->stream, h->dp,
-                           h->ds, h->wp, dev_active);
-        HIP_TRY(hipGetLastError());
+        if (h->xt.p) {
+            if (int rc = launch_wide_scan(h, dev_active))
+                return rc;
+        } else {
+            int parts = 1;
+            while (h->batch * parts * 2 <= 1024 && h->m / (parts * 2) >= 8)
+                parts *= 2;
+            hipLaunchKernelGGL(bxh::wide_flags_kernel, dim3(h->batch * parts), dim3(512), 0, h->stream,
+                               h->dp, h->ds, h->wp, dev_active, parts);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(bxh::wide_compact_kernel, dim3(h->batch), dim3(512), 0, h->stream, h->dp,
+                               h->ds, h->wp, dev_active);
+            HIP_TRY(hipGetLastError());
+        }
         if (remaining) {
             HIP_TRY(hipStreamSynchronize(h->stream));
             HIP_TRY(hipMemcpy(h->h_status, h->status.p,
@@ -2382,6 +2434,9 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
     if (int rc = h->float_type == BXH_FLOAT ? launch_sweep<float>(h, s)
                                              : launch_sweep<double>(h, s))
         return rc;
+    if (h->version == 4 && h->wp.skip_scan) // compute_violated_constraints, all instances in one pass
+        if (int rc = launch_wide_scan(h, s.active))
+            return rc;
     if (need_post) { // m_order of the new x (itm-common.hpp:893-914)
         if (h->float_type == BXH_FLOAT)
             hipLaunchKernelGGL((bxh::order_post_kernel<float>), dim3(h->batch), dim3(h->threads),

@@ -73,6 +73,9 @@ struct WideParams
     unsigned long long* bkey;  // [batch][G][n2big] sort scratch of long rows
     int* bid;                  // [batch][G][n2big]
     int* vflag32;              // [batch][m] violated flags of the end-of-sweep scan
+    unsigned* xt;              // [n] x of all instances, one bit per instance (batch <= 32), or null
+    int skip_scan;             // 1: the sweep kernel leaves compute_violated_constraints to
+                               //    wide_flags_all_kernel (one pass over A for all instances)
 };
 
 __host__ __device__ inline int
@@ -1967,6 +1970,18 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
     if (grp == 0)
         for (int i = tid; i < m; i += T)
             pig[i] = piw[i];
+    if (wp.skip_scan) { // the scan follows in its own launch, shared by the instances
+        if (grp == 0 && tid == 0) {
+            DevStatus s = st.status[inst];
+            s.pi_changed = misc_s[MS_PICH];
+            s.rng = rng.s;
+            s.rows_in_sweep = (unsigned)nrows;
+            s.row_updates += (unsigned long long)nrows;
+            s.alg_bytes += alg_bytes;
+            st.status[inst] = s;
+        }
+        return;
+    }
     {
         const int per = (m + G - 1) / G;
         const int k0 = grp * per, k1 = min(m, k0 + per);
@@ -2055,6 +2070,60 @@ wide_flags_kernel(DevProblem pb, DevState st, WideParams wp, const unsigned char
         v = wave_sum(v);
         if (lane == 0)
             vf[k] = !(pb.bmin[k] <= v && v <= pb.bmax[k]);
+    }
+}
+
+// compute_violated_constraints of ALL instances in one pass over A: x is
+// transposed first (one word per variable, bit b = x of instance b), then a wave
+// per row adds up, per instance, the bits of the row's columns -- the matrix
+// (8 GB at the XL shape) is read once instead of once per instance.
+__global__ __launch_bounds__(256) void
+wide_transpose_kernel(DevProblem pb, DevState st, unsigned* xt, int batch)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= pb.n)
+        return;
+    unsigned word = 0;
+    for (int b = 0; b < batch; ++b)
+        word |= ((st.x[(size_t)b * (2 * pb.nwords) + (j >> 5)] >> (j & 31)) & 1u) << b;
+    xt[j] = word;
+}
+
+template<int NB> // instances handled (16 / 32)
+__global__ __launch_bounds__(512) void
+wide_flags_all_kernel(DevProblem pb, WideParams wp, const unsigned* xt, const unsigned char* active,
+                      int batch)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool pm1 = pb.kind == 2 || pb.kind == 3;
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int k = blockIdx.x * (blockDim.x >> 6) + wave; k < pb.m; k += nwaves) {
+        const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
+        int cnt[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            cnt[b] = 0;
+        for (int e = rs + lane; e < re; e += 64) {
+            const unsigned w = xt[pb.row_col[e]];
+            if (pm1) {
+                const int sgn = (int)pb.fac_csr[e];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    cnt[b] += (int)((w >> b) & 1u) * sgn;
+            } else {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    cnt[b] += (int)((w >> b) & 1u);
+            }
+        }
+        const int lo = pb.bmin[k], hi = pb.bmax[k];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int v = wave_sum(cnt[b]);
+            if (lane == 0 && b < batch && (!active || active[b]))
+                wp.vflag32[(size_t)b * pb.m + k] = !(lo <= v && v <= hi);
+        }
     }
 }
 

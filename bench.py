@@ -625,7 +625,10 @@ def main():
         # algorithmic bytes: B(k) summed on the device over every
         # row updated, plus the violated-row scan of every instance and sweep
         mean_row_bytes = (bytes1 - bytes0) / max(rows_total, 1)
-        alg = (bytes1 - bytes0) + args.steps * wl.batch * wl.scan_bytes
+        # (the violated-row scan belongs to the sweep kernel's bytes only where it
+        # runs inside that kernel: the wide kernel's is a launch of its own)
+        scan = wl.scan_bytes if dev.sweep_includes_scan else 0.0
+        alg = (bytes1 - bytes0) + args.steps * wl.batch * scan
         per_launch_bytes = alg / max(launches, 1)
         per_launch_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0

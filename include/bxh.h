@@ -172,6 +172,10 @@ int bxh_rmax(bxh_handle h);
  *   100 + g wide kernel (columns / row counts beyond the staged kernel: the XL
  *           shape), g workgroups per instance share every row */
 int bxh_kernel_form(bxh_handle h);
+/* 1: compute_violated_constraints runs inside the sweep kernel (its bytes belong
+ * to that kernel's roofline); 0: in launches of its own behind it (the wide
+ * kernel with at most 32 instances: one pass over A for all of them) */
+int bxh_sweep_includes_scan(bxh_handle h);
 
 /* Solver fields x / pi / P (P in CSR element order, as `slv.P[e]`), and the
  * worker's random engine. `inst` in [0, batch). */
