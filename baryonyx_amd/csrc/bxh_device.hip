@@ -1228,8 +1228,6 @@ bxh_create(const bxh_problem* pb,
         wp.bkey = h->bkey.p;
         wp.bid = h->bid.p;
         wp.vflag32 = h->vflag32.p;
-    wp.xt = h->xt.p;
-    wp.skip_scan = h->xt.p ? 1 : 0;
         wp.xt = h->xt.p;
         wp.skip_scan = h->xt.p ? 1 : 0;
         const int wl = static_cast<int>(h->lds_bytes);
@@ -1729,6 +1727,8 @@ bxh_create_device(const bxh_problem* pb,
     wp.bkey = h->bkey.p;
     wp.bid = h->bid.p;
     wp.vflag32 = h->vflag32.p;
+    wp.xt = h->xt.p;
+    wp.skip_scan = h->xt.p ? 1 : 0;
     const int wlb = static_cast<int>(h->lds_bytes);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, wlb));
