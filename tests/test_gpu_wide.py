@@ -68,6 +68,16 @@ def test_wide_kernel_long_rows_tied_runs_side_by_side(oracle, bxh, ncost, monkey
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=3, push_at=(2,), expect_form=104)
 
 
+def test_wide_kernel_bench_geometry(oracle, bxh, monkeypatch):
+    """16 instances x 16 workgroups = one workgroup per CU, the launch geometry of
+    `bench.py --config c4` (and the 16-instance form of the shared violated scan),
+    on an instance the oracle replays in seconds: every instance of the batch is
+    compared after every sweep."""
+    monkeypatch.setenv("BXH_GROUPS", "w16")
+    inst = synth.make_scp(3000, 2500, 0.08, "real", 131)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=16, sweeps=2, push_at=(1,), expect_form=116)
+
+
 def test_wide_kernel_is_chosen_for_long_columns(oracle, bxh, monkeypatch):
     """Columns of ~300 entries: bxh_create picks the wide kernel by itself."""
     monkeypatch.delenv("BXH_GROUPS", raising=False)
