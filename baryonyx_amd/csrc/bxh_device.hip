@@ -1948,8 +1948,11 @@ bxh_pop_set(bxh_handle h, int slot, const uint64_t* words)
     if (!words)
         return fail(BXH_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(h->pop.p + static_cast<size_t>(slot) * 2 * h->nwords, words,
-                           static_cast<size_t>(h->nwords) * 8, hipMemcpyHostToDevice, h->stream));
+    // after what is queued (restarts that read the slot as it was), and over when
+    // the call returns (the caller's vector may change)
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->pop.p + static_cast<size_t>(slot) * 2 * h->nwords, words,
+                      static_cast<size_t>(h->nwords) * 8, hipMemcpyHostToDevice));
     return BXH_OK;
 }
 
@@ -2009,8 +2012,11 @@ bxh_reinit(bxh_handle h, int njobs, const bxh_reinit_job* jobs)
         HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(h->jobs_d.alloc(static_cast<size_t>(std::max(njobs, h->batch))));
     }
-    HIP_TRY(hipMemcpyAsync(h->jobs_d.p, jobs, static_cast<size_t>(njobs) * sizeof(bxh_reinit_job),
-                           hipMemcpyHostToDevice, h->stream));
+    // (the jobs of the previous call have been read: the stream is in order and the
+    // copy below is a blocking one from pageable memory)
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->jobs_d.p, jobs, static_cast<size_t>(njobs) * sizeof(bxh_reinit_job),
+                      hipMemcpyHostToDevice));
     hipLaunchKernelGGL(bxh::reinit_kernel, dim3(njobs), dim3(64), 0, h->stream, h->dp, h->ds, h->jobs_d.p,
                        h->pop.p);
     HIP_TRY(hipGetLastError());
