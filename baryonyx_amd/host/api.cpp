@@ -9,6 +9,13 @@
 
 namespace baryonyx {
 
+optimize_timing&
+last_optimize_timing()
+{
+    static thread_local optimize_timing t;
+    return t;
+}
+
 static void
 context_deleter(context* ctx)
 {

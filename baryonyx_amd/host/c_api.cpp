@@ -46,6 +46,17 @@ struct bxc_result
     double value, recomputed_value, duration;
 };
 
+// wall-clock phases of the calling thread's last optimize(): host set-up,
+// device set-up, rounds (seconds)
+BX_EXPORT void
+bxc_last_optimize_timing(double* out3)
+{
+    const optimize_timing& t = last_optimize_timing();
+    out3[0] = t.host_setup;
+    out3[1] = t.device_setup;
+    out3[2] = t.rounds;
+}
+
 BX_EXPORT void
 bxc_default_params(bxc_params* p)
 {

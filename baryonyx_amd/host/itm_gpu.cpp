@@ -1242,6 +1242,17 @@ optimize_problem(const context& ctx, const problem& pb)
     if (ctx.start)
         ctx.start(ctx.parameters);
 
+    const bool timing = std::getenv("BXC_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since_begin = [&]() {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    };
+    auto lap = [&](const char* what) {
+        if (timing)
+            std::fprintf(stderr, "optimize: %-28s %8.3f ms\n", what, since_begin() * 1e3);
+    };
+    optimize_timing& tm = last_optimize_timing();
+    tm = optimize_timing{};
     const auto constraints = make_merged_constraints(ctx, pb);
     const int variables = static_cast<int>(pb.vars.values.size());
     if (constraints.empty() || pb.vars.values.empty()) {
@@ -1251,6 +1262,7 @@ optimize_problem(const context& ctx, const problem& pb)
         fill_result(r, pb, variables, 0);
         return r;
     }
+    lap("merged constraints");
     const auto& p = ctx.parameters;
     const bool maximize = pb.type == objective_function_type::maximize;
     random_engine rng(seed_of(ctx));
@@ -1291,6 +1303,8 @@ optimize_problem(const context& ctx, const problem& pb)
     const long w_limit = static_cast<long>(p.w);
     const int order = static_cast<int>(p.order);
 
+    lap("merged constraints, recorder");
+    tm.host_setup = since_begin();
     device_pool slv(ctx, constraints, variables, norm_costs, device_kind(pb.problem_type),
                     maximize, workers);
 
@@ -1328,6 +1342,8 @@ optimize_problem(const context& ctx, const problem& pb)
                 slv.pop_set_all(slot, x);
         };
     }
+    lap("device pool + population");
+    tm.device_setup = since_begin() - tm.host_setup;
     const int blocks = wk[0].x.block_size();
     if (device_population && blocks != slv.dev[0]->nwords)
         throw std::runtime_error("bit_array blocks != device words");
@@ -1499,6 +1515,8 @@ optimize_problem(const context& ctx, const problem& pb)
         }
     }
 
+    lap("rounds");
+    tm.rounds = since_begin() - tm.host_setup - tm.device_setup;
     // diagnostic (tests): every device's copy of the population == the host's
     if (device_population && std::getenv("BXC_CHECK_POP")) {
         bit_array got(variables);

@@ -45,6 +45,16 @@ struct context
 
 // What optimize() leaves behind for the parity tests (population best first,
 // every worker's engine and restart count): filled when context::trace is set.
+// wall-clock phases of the last optimize() of this thread (seconds): the host's
+// set-up (merged constraints, costs, the initial population with its pre-solves
+// and evaluations -- what the reference does in storage's constructor), the
+// device set-up (handles, population upload) and the rounds themselves
+struct optimize_timing
+{
+    double host_setup = 0, device_setup = 0, rounds = 0;
+};
+optimize_timing& last_optimize_timing();
+
 struct optimize_trace
 {
     std::vector<int> pop_remaining;

@@ -188,6 +188,13 @@ def preprocess(path, fix_zero=None, affect=None, split=None):
                 quadratic=[(int(qa[i]), int(qb[i]), float(qf[i])) for i in range(info.n_quadratic)])
 
 
+def last_optimize_timing():
+    """(host set-up, device set-up, rounds) of this thread's last optimize(), seconds."""
+    out = (C.c_double * 3)()
+    lib().bxc_last_optimize_timing(out)
+    return float(out[0]), float(out[1]), float(out[2])
+
+
 def optimize_trace(path, params, nvars):
     """baryonyx::optimize with the recorder's final state: (Result, dict) with
     the population best first (x over the `nvars` preprocessed variables), every
