@@ -24,6 +24,7 @@
 #include <cstring>
 #include <numeric>
 #include <sstream>
+#include <thread>
 
 namespace baryonyx {
 namespace itm {
@@ -972,7 +973,9 @@ struct recorder
             init_with_pre_solve(data[i].x, data[i + 1].x, rng, costs, maximize, csts,
                                 std::clamp(static_cast<double>(i) / (5 * e), 0.0, 1.0));
         }
-        for (int i = 0; i != size; ++i) {
+        // hash, objective and violated rows of every start point: independent of
+        // each other (no draw involved), so on the host's cores
+        auto evaluate = [&](int i) {
             data[i].hash = hash_of(data[i].x);
             data[i].value = costs.results(data[i].x, cost_constant);
             data[i].remaining_constraints = 0;
@@ -984,6 +987,20 @@ struct recorder
                 if (!(cst.min <= sum && sum <= cst.max))
                     ++data[i].remaining_constraints;
             }
+        };
+        {
+            const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+            const int nt = std::max(1, std::min<int>(static_cast<int>(hw), size));
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; ++t)
+                pool.emplace_back([&, t]() {
+                    for (int i = t; i < size; i += nt)
+                        evaluate(i);
+                });
+            for (int i = 0; i < size; i += nt)
+                evaluate(i);
+            for (auto& th : pool)
+                th.join();
         }
         std::iota(indices.begin(), indices.end(), 0);
         sort();

@@ -59,7 +59,7 @@ def build(force: bool = False) -> str:
         stale = any(os.path.getmtime(s) > t for s in srcs) or os.path.getmtime(bxh) > t
     if stale:
         subprocess.check_call(
-            ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+            ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-pthread",
              "-I" + os.path.join(_HERE, "..", "include"), "-o", LIB_PATH,
              *[os.path.join(HOST, s) for s in SOURCES],
              "-L" + os.path.join(_HERE, "csrc"), "-lbxh", "-Wl,-rpath,$ORIGIN/../csrc"])
