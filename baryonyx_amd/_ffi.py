@@ -30,7 +30,7 @@ BXH_ERR_DEVICE = -4
 # every symbol include/bxh.h declares (tests check the library exports them)
 SYMBOLS = [
     "bxh_last_error", "bxh_create", "bxh_create_device", "bxh_destroy", "bxh_set_stream", "bxh_batch",
-    "bxh_nwords", "bxh_rmax", "bxh_kernel_form", "bxh_sweep_includes_scan", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_get_x_all", "bxh_set_rng_all", "bxh_pop_create", "bxh_pop_set", "bxh_pop_get", "bxh_pop_store", "bxh_reinit", "bxh_set_pi", "bxh_get_pi",
+    "bxh_nwords", "bxh_rmax", "bxh_kernel_form", "bxh_sweep_includes_scan", "bxh_run_supported", "bxh_run", "bxh_get_best_x", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_get_x_all", "bxh_set_rng_all", "bxh_pop_create", "bxh_pop_set", "bxh_pop_get", "bxh_pop_store", "bxh_reinit", "bxh_set_pi", "bxh_get_pi",
     "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset", "bxh_reset_all",
     "bxh_order_create", "bxh_order_init", "bxh_order_init_masked", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
     "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time",
@@ -144,6 +144,9 @@ def lib():
         L.bxh_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         for nm in ("bxh_batch", "bxh_nwords", "bxh_rmax", "bxh_kernel_form"):
             getattr(L, nm).argtypes = [C.c_void_p]
+        L.bxh_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bxh_get_best_x.argtypes = [C.c_void_p, C.c_int, u64p]
+        L.bxh_run_supported.argtypes = [C.c_void_p]
         L.bxh_set_x.argtypes = [C.c_void_p, C.c_int, u64p]
         L.bxh_get_x.argtypes = [C.c_void_p, C.c_int, u64p]
         L.bxh_set_x_all.argtypes = [C.c_void_p, u64p]
@@ -181,6 +184,17 @@ def _check(rc):
 
 def _p(a, typ):
     return a.ctypes.data_as(typ)
+
+
+class RunArgs(C.Structure):
+    _fields_ = [("kappa", C.POINTER(C.c_double)), ("delta", C.c_double), ("theta", C.c_double),
+                ("order", C.c_int), ("max_sweeps", C.c_int), ("first_i", C.c_int), ("w_limit", C.c_int),
+                ("kappa_max", C.c_double), ("kappa_inc", C.POINTER(C.c_double)),
+                ("active", C.POINTER(C.c_ubyte))]
+
+
+RUN_STATUS_DTYPE = np.dtype([("sweeps", np.int32), ("best_remaining", np.int32), ("best_i", np.int32),
+                             ("stop", np.int32), ("kappa", np.float64)])
 
 
 class DeviceBatch:
@@ -373,6 +387,38 @@ class DeviceBatch:
         a, keep = self._args(kappa, delta, theta, is_push, obj_amp, order, active)
         _check(self.L.bxh_sweep(self.h, C.byref(a), self._status.ctypes.data_as(C.c_void_p)))
         return self._status.copy()
+
+    def run(self, kappa, delta, theta, order, max_sweeps, first_i, w_limit, kappa_max, kappa_inc):
+        """bxh_run: up to max_sweeps sweeps of solver_functor's loop in one launch;
+        returns (status array, run status array)."""
+        k = np.ascontiguousarray(np.broadcast_to(np.asarray(kappa, np.float64), (self.batch,)).copy())
+        inc = np.ascontiguousarray(kappa_inc, np.float64)
+        a = RunArgs(k.ctypes.data_as(C.POINTER(C.c_double)), float(delta), float(theta), int(order),
+                    int(max_sweeps), int(first_i), int(w_limit), float(kappa_max),
+                    inc.ctypes.data_as(C.POINTER(C.c_double)), None)
+        rs = np.zeros(self.batch, RUN_STATUS_DTYPE)
+        _check(self.L.bxh_run(self.h, C.byref(a), self._status.ctypes.data_as(C.c_void_p),
+                              rs.ctypes.data_as(C.c_void_p)))
+        return self._status.copy(), rs
+
+    def run_masked(self, kappa, delta, theta, order, max_sweeps, first_i, w_limit, kappa_max, kappa_inc,
+                   active):
+        """bxh_run for the instances `active` selects (uint8 per instance)."""
+        k = np.ascontiguousarray(np.broadcast_to(np.asarray(kappa, np.float64), (self.batch,)).copy())
+        inc = np.ascontiguousarray(kappa_inc, np.float64)
+        act = np.ascontiguousarray(active, np.uint8)
+        a = RunArgs(k.ctypes.data_as(C.POINTER(C.c_double)), float(delta), float(theta), int(order),
+                    int(max_sweeps), int(first_i), int(w_limit), float(kappa_max),
+                    inc.ctypes.data_as(C.POINTER(C.c_double)), act.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        rs = np.zeros(self.batch, RUN_STATUS_DTYPE)
+        _check(self.L.bxh_run(self.h, C.byref(a), self._status.ctypes.data_as(C.c_void_p),
+                              rs.ctypes.data_as(C.c_void_p)))
+        return self._status.copy(), rs
+
+    def get_best_x(self, i):
+        w = np.zeros(self.nwords, np.uint64)
+        _check(self.L.bxh_get_best_x(self.h, int(i), w.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return w
 
     def sweep_async(self, kappa, delta, theta, is_push=False, obj_amp=0.0, order=0, active=None):
         a, keep = self._args(kappa, delta, theta, is_push, obj_amp, order, active)

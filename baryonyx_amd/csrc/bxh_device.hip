@@ -108,6 +108,10 @@ struct bxh_handle_s
     int narrow_w = 0, narrow_rpq = 0; // narrow kernel (version 5): waves per instance, staged row positions / 64
     DevBuf<int4> ndesc;        // narrow kernel: per CSR element descriptors
     bxh::NarrowParams npar{};
+    bxh::NarrowRun nrun{};          // (max_sweeps == 0 outside bxh_run)
+    DevBuf<int> run_out;            // [batch][4]
+    DevBuf<double> run_kappa, run_inc; // [batch], [m + 1]
+    DevBuf<unsigned> run_xbest;     // [batch][2 * nwords]
     bool device_built = false; // bxh_create_device: no host copy of the matrix exists
     // 1: the instance's list R is known to be empty (a sweep over it is a no-op);
     // 0: unknown or not empty.  Maintained by the calls that read `remaining` back.
@@ -356,7 +360,7 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
     } else if (h->version == 5) {
 #define BXH_NARROW(PM, WW, RQ)                                                 \
     hipLaunchKernelGGL((bxh::sweep_kernel_narrow<Float, PM, WW, RQ>), dim3(h->batch), dim3(64 * WW), \
-                       h->lds_bytes, h->stream, h->dp, h->ds, a, h->npar)
+                       h->lds_bytes, h->stream, h->dp, h->ds, a, h->npar, h->nrun)
 #define BXH_NARROW_W(PM, WW)                                                   \
     do {                                                                       \
         if (h->narrow_rpq == 1)                                                \
@@ -2452,6 +2456,89 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
                                h->lds_bytes_init, h->stream, h->dp, h->ds, s);
         HIP_TRY(hipGetLastError());
     }
+    return BXH_OK;
+}
+
+int
+bxh_run_supported(bxh_handle h)
+{
+    return (h && h->version == 5) ? 1 : 0;
+}
+
+int
+bxh_run(bxh_handle h, const bxh_run_args* a, bxh_status* status_out, bxh_run_status* run_out)
+{
+    if (!h || !a || !a->kappa || !a->kappa_inc)
+        return fail(BXH_ERR_INVALID, "null argument");
+    if (h->version != 5)
+        return fail(BXH_ERR_UNSUPPORTED, "bxh_run: only the short-row kernel runs several sweeps per launch");
+    if (a->order > BXH_ORDER_RANDOM_SORTING)
+        return fail(BXH_ERR_UNSUPPORTED, "bxh_run: row orders none / reversing / random_sorting only");
+    if (a->max_sweeps <= 0)
+        return fail(BXH_ERR_INVALID, "bxh_run: max_sweeps must be positive");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = static_cast<size_t>(h->batch);
+    if (!h->run_out.p) {
+        HIP_TRY(h->run_out.alloc(B * 4));
+        HIP_TRY(h->run_kappa.alloc(B));
+        HIP_TRY(h->run_inc.alloc(static_cast<size_t>(h->m) + 1));
+        HIP_TRY(h->run_xbest.alloc(B * 2 * h->nwords));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->run_inc.p, a->kappa_inc, (static_cast<size_t>(h->m) + 1) * sizeof(double),
+                      hipMemcpyHostToDevice));
+    h->nrun.max_sweeps = a->max_sweeps;
+    h->nrun.first_i = a->first_i;
+    h->nrun.w_limit = a->w_limit;
+    h->nrun.kappa_max = a->kappa_max;
+    h->nrun.kappa_inc = h->run_inc.p;
+    h->nrun.out = h->run_out.p;
+    h->nrun.kappa_out = h->run_kappa.p;
+    h->nrun.xbest = h->run_xbest.p;
+    bxh_sweep_args sa{};
+    sa.kappa = a->kappa;
+    sa.delta = a->delta;
+    sa.theta = a->theta;
+    sa.obj_amp = 0.0;
+    sa.is_push = 0;
+    sa.order = a->order;
+    sa.active = a->active;
+    // (a launch of several sweeps is never skipped: its first list may be empty, the lists
+    // behind it are not known here)
+    h->known_empty.assign(B, 0);
+    int rc = bxh_sweep_async(h, &sa);
+    h->nrun = bxh::NarrowRun{};
+    if (rc)
+        return rc;
+    if (int rc2 = bxh_status_sync(h, status_out))
+        return rc2;
+    if (run_out) {
+        std::vector<int> ro(B * 4);
+        std::vector<double> ko(B);
+        HIP_TRY(hipMemcpy(ro.data(), h->run_out.p, B * 4 * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ko.data(), h->run_kappa.p, B * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b != B; ++b) {
+            run_out[b].sweeps = ro[b * 4];
+            run_out[b].best_remaining = ro[b * 4 + 1];
+            run_out[b].best_i = ro[b * 4 + 2];
+            run_out[b].stop = ro[b * 4 + 3];
+            run_out[b].kappa = ko[b];
+        }
+    }
+    return BXH_OK;
+}
+
+int
+bxh_get_best_x(bxh_handle h, int inst, uint64_t* words)
+{
+    if (int rc = check_inst(h, inst))
+        return rc;
+    if (!words || !h->run_xbest.p)
+        return fail(BXH_ERR_INVALID, "bxh_get_best_x: no run yet");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(words, h->run_xbest.p + static_cast<size_t>(inst) * 2 * h->nwords,
+                      static_cast<size_t>(h->nwords) * 8, hipMemcpyDeviceToHost));
     return BXH_OK;
 }
 

@@ -47,9 +47,26 @@ struct NarrowParams
                       //  {cost of the column as Float bits, 0, 0}
 };
 
+// Several sweeps of solver_functor's loop (itm-solver-common.hpp:135-213) in one
+// launch: after every sweep the instance's kappa moves as the host would move
+// it, the launch ends when no row is violated, when kappa passes kappa_max or
+// after max_sweeps; pi, x and the row list stay in LDS in between.  max_sweeps
+// == 0: one sweep, nothing of this (bxh_sweep).
+struct NarrowRun
+{
+    int max_sweeps;
+    int first_i;             // loop index of the launch's first sweep
+    int w_limit;             // kappa moves behind a sweep with index > w_limit
+    double kappa_max;
+    const double* kappa_inc; // [m + 1] what kappa gains behind a sweep that left that many rows
+    int* out;                // [batch][4] sweeps done, fewest rows left, its sweep index, why it ended
+    double* kappa_out;       // [batch]
+    unsigned* xbest;         // [batch][2 * nwords] x behind the sweep that left the fewest rows
+};
+
 struct NarrowLds
 {
-    int off_pi, off_x, off_rows, off_rowc, off_slot, off_desc, off_cols, off_val, off_key, off_id,
+    int off_pi, off_x, off_xbest, off_rows, off_rowc, off_slot, off_desc, off_cols, off_val, off_key, off_id,
       off_tab, off_rank, off_stale, off_misc, off_part, total, n2;
     int rp;        // row positions staged (64 * RPQ)
     int desc_size; // bytes of one descriptor buffer
@@ -73,6 +90,8 @@ narrow_lds(int m, int n, int nwords, int rmax, int fsize, int rpq)
     p.off_pi = o;
     o = al(o + (m + 1) * fsize);
     p.off_x = o;
+    o = al(o + nwords * 8);
+    p.off_xbest = o; // (several sweeps per launch) x behind the best sweep so far
     o = al(o + nwords * 8);
     p.off_rows = o;
     o = al(o + m * 4);
@@ -206,7 +225,7 @@ typedef unsigned narrow_v4u __attribute__((ext_vector_type(4)));
 // the rest on demand.
 template<typename Float, bool PM1, int W, int RPQ>
 __global__ __launch_bounds__(64 * W) void
-sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
+sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, NarrowRun run)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int inst = blockIdx.x;
@@ -226,6 +245,7 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
     const NarrowLds L = narrow_lds(pb.m, pb.n, pb.nwords, pb.rmax, FS, RPQ);
     Float* pi_s = (Float*)(smem + L.off_pi);
     unsigned* x_s = (unsigned*)(smem + L.off_x);
+    unsigned* xbest_s = (unsigned*)(smem + L.off_xbest);
     int* rows_s = (int*)(smem + L.off_rows);
     int4* rowc_s = (int4*)(smem + L.off_rowc);
     unsigned char* slot_s = smem + L.off_slot;
@@ -256,14 +276,14 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
     const Float* cost = (const Float*)pb.cost;
     const unsigned short* ids16 = pb.col_row16;
 
-    const Float kappa = (Float)a.kappa[inst];
+    Float kappa = (Float)a.kappa[inst];
     const Float delta = (Float)a.delta;
     const Float theta = (Float)a.theta;
     const Float obj_amp = (Float)a.obj_amp;
     const bool push = a.is_push != 0;
-    const Float kfac = kappa / ((Float)1 - kappa);
+    Float kfac = kappa / ((Float)1 - kappa);
 
-    const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
+    int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
     for (int i = tid; i < pb.m; i += T)
         pi_s[i] = pig[i];
     if (tid == 0)
@@ -301,12 +321,20 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
         ps[12] = 0ull;  // tie flag
         ps[13] = ~0ull; // smallest key
     };
+    int cnt = 0;                  // rows violated behind the last sweep
+    int sweeps_done = 0, stop_why = 0;
+    int best_rem = 0x7fffffff, best_i = 0;
+    unsigned long long rows_total = 0;
+    double alg_total = 0.0;
+    unsigned rows_last = 0;
+    for (int sw = 0;; ++sw) { // (one pass unless run.max_sweeps says otherwise)
     if (tid == 0) {
         misc_s[MS_PICH] = 0;
         part_reset(part_all);
         part_reset(part_all + 16);
     }
     __syncthreads();
+    kfac = kappa / ((Float)1 - kappa);
     // compute_order: random_sorting shuffles the list before the sweep
     // (itm-common.hpp:708-714 / :817-823)
     if (ord == 2 || ord == 7) {
@@ -948,14 +976,8 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
         BXH_PSTAMP(&prof, 7);
     }
 
-    // ---- write back, then compute_violated_constraints ---------------------
+    // ---- compute_violated_constraints ----------------------------------------
     __syncthreads();
-    for (int i = tid; i < pb.m; i += T)
-        pig[i] = pi_s[i];
-    for (int i = tid; i < 2 * pb.nwords; i += T)
-        xg[i] = x_s[i];
-    for (int i = tid; i <= pb.rmax; i += T)
-        staleg[i] = stale_s[i];
     if (ord == 7) // pi_sign_change keeps the shuffled R
         for (int i = tid; i < nrows; i += T)
             vlist[i] = rows_s[i];
@@ -1011,7 +1033,7 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
         }
     }
     __syncthreads();
-    int cnt = 0;
+    cnt = 0;
     {
         int* scratch_s = misc_s + MS_WAVES;
         for (int c = 0; c < pb.m; c += T) {
@@ -1036,11 +1058,64 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
                     tot += cw;
                 }
             }
-            if (f)
+            if (f) {
                 out_list[cnt + off + prefix] = kq;
+                if (!keep)
+                    rows_s[cnt + off + prefix] = kq; // (the list of the next sweep of this launch)
+            }
             cnt += tot;
             if (W > 1)
                 __syncthreads();
+        }
+    }
+    // ---- solver_functor's bookkeeping behind a sweep (every thread alike) ------
+    rows_total += (unsigned long long)nrows;
+    alg_total += alg_bytes;
+    rows_last = (unsigned)nrows;
+    sweeps_done = sw + 1;
+    if (run.max_sweeps <= 0)
+        break;
+    {
+        const int i = run.first_i + sw;
+        if (cnt == 0)
+            stop_why = 1;
+        else {
+            if (cnt < best_rem) {
+                best_rem = cnt;
+                best_i = i;
+                for (int w = tid; w < 2 * pb.nwords; w += T)
+                    xbest_s[w] = x_s[w];
+            }
+            if (i > run.w_limit)
+                kappa = kappa + (Float)run.kappa_inc[cnt];
+            if (kappa > (Float)run.kappa_max)
+                stop_why = 2;
+        }
+        if (stop_why || sw + 1 >= run.max_sweeps)
+            break;
+    }
+    nrows = cnt;
+    __syncthreads();
+    } // sweeps of this launch
+
+    // ---- write back ---------------------------------------------------------------
+    __syncthreads();
+    for (int i = tid; i < pb.m; i += T)
+        pig[i] = pi_s[i];
+    for (int i = tid; i < 2 * pb.nwords; i += T)
+        xg[i] = x_s[i];
+    for (int i = tid; i <= pb.rmax; i += T)
+        staleg[i] = stale_s[i];
+    if (run.max_sweeps > 0) {
+        if (best_rem != 0x7fffffff)
+            for (int i = tid; i < 2 * pb.nwords; i += T)
+                run.xbest[(size_t)inst * (2 * pb.nwords) + i] = xbest_s[i];
+        if (tid == 0) {
+            run.out[inst * 4 + 0] = sweeps_done;
+            run.out[inst * 4 + 1] = best_rem;
+            run.out[inst * 4 + 2] = best_i;
+            run.out[inst * 4 + 3] = stop_why;
+            run.kappa_out[inst] = (double)kappa;
         }
     }
 
@@ -1057,9 +1132,9 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np)
         s.remaining = cnt;
         s.pi_changed = misc_s[MS_PICH];
         s.rng = rng.s;
-        s.rows_in_sweep = (unsigned)nrows;
-        s.row_updates += (unsigned long long)nrows;
-        s.alg_bytes += alg_bytes;
+        s.rows_in_sweep = rows_last;
+        s.row_updates += rows_total;
+        s.alg_bytes += alg_total;
         st.status[inst] = s;
     }
 }

@@ -455,6 +455,27 @@ struct device_batch
         check(bxh_sweep_async(h, &a));
     }
     void sync() { check(bxh_status_sync(h, status.data())); }
+    // several sweeps of solver_functor's loop in one launch (bxh_run)
+    bool run_supported() const { return bxh_run_supported(h) != 0; }
+    bxh_run_status run(double delta, double theta, int order, int max_sweeps, long first_i, long w_limit,
+                       double kappa_max, const std::vector<double>& kappa_inc)
+    {
+        bxh_run_args a{};
+        a.kappa = kappa.data();
+        a.delta = delta;
+        a.theta = theta;
+        a.order = order;
+        a.max_sweeps = max_sweeps;
+        a.first_i = static_cast<int>(std::min<long>(first_i, 0x7fffffff - max_sweeps));
+        a.w_limit = static_cast<int>(std::min<long>(w_limit, 0x7fffffff));
+        a.kappa_max = kappa_max;
+        a.kappa_inc = kappa_inc.data();
+        a.active = active.data();
+        std::vector<bxh_run_status> rs(static_cast<size_t>(batch));
+        check(bxh_run(h, &a, status.data(), rs.data()));
+        return rs[0];
+    }
+    void get_best_x(int i, bit_array& x) { check(bxh_get_best_x(h, i, x.w.data())); }
     // x / engine state of every instance in one transfer
     void get_x_all(std::uint64_t* words) { check(bxh_get_x_all(h, words)); }
     void set_x_all(const std::uint64_t* words) { check(bxh_set_x_all(h, words)); }
@@ -807,7 +828,55 @@ solve_problem(const context& ctx, const problem& pb)
         slv.order_create(order);
         slv.order_init(order);
 
-        for (long i = 0; i != p.limit; ++i) {
+        // Short rows: the loop below runs on the device, up to 256 sweeps per launch
+        // (bxh_run: kappa moves there, by the increments worked out here in Float);
+        // BXC_SINGLE_SWEEPS=1 keeps one launch per sweep.
+        const bool many = slv.run_supported() && order <= 2 && !std::getenv("BXC_SINGLE_SWEEPS");
+        std::vector<double> kappa_inc;
+        if (many) {
+            kappa_inc.resize(static_cast<size_t>(slv.m) + 1);
+            for (int r = 0; r <= slv.m; ++r)
+                kappa_inc[static_cast<size_t>(r)] = static_cast<double>(static_cast<Float>(
+                  kappa_step * std::pow(static_cast<Float>(r) / static_cast<Float>(slv.m), alpha)));
+        }
+        bool main_done = false;
+        if (many) {
+            main_done = true;
+            long i = 0;
+            while (i != p.limit) {
+                const long left = p.limit < 0 ? 256 : p.limit - i;
+                const int chunk = static_cast<int>(std::min<long>(left, 256));
+                slv.kappa[0] = static_cast<double>(kappa);
+                const bxh_run_status rs = slv.run(static_cast<double>(delta), static_cast<double>(theta), order,
+                                                  chunk, i, w_limit, static_cast<double>(kappa_max), kappa_inc);
+                if (rs.best_remaining != INT_MAX && rs.best_remaining < best_remaining) {
+                    if (best_remaining_constraints > rs.best_remaining) { // store_remaining
+                        slv.get_best_x(0, x);
+                        best_x = x;
+                        best_loop = rs.best_i;
+                        best_remaining_constraints = rs.best_remaining;
+                    }
+                    best_remaining = rs.best_remaining;
+                }
+                kappa = static_cast<Float>(rs.kappa);
+                if (rs.stop == 1) {
+                    store_value(i + rs.sweeps - 1);
+                    best_remaining = 0;
+                    start_push = true;
+                    break;
+                }
+                if (rs.stop == 2) {
+                    ret.status = result_status::kappa_max_reached;
+                    break;
+                }
+                i += rs.sweeps;
+                if (timeout()) {
+                    ret.status = result_status::time_limit_reached;
+                    break;
+                }
+            }
+        }
+        for (long i = 0; !main_done && i != p.limit; ++i) {
             slv.kappa[0] = static_cast<double>(kappa);
             slv.sweep(static_cast<double>(delta), static_cast<double>(theta), false, 0.0, order);
             const int remaining = slv.status[0].remaining;
@@ -848,6 +917,32 @@ solve_problem(const context& ctx, const problem& pb)
                     store_value(-push * p.pushing_iteration_limit - 1);
                 if (timeout())
                     break;
+                if (many && p.pushing_iteration_limit > 0) {
+                    // the iterations behind a push sweep: the same loop, on the device
+                    bool out_of_time = false;
+                    int iter = 0;
+                    while (iter < p.pushing_iteration_limit) {
+                        const int chunk = std::min(p.pushing_iteration_limit - iter, 256);
+                        slv.kappa[0] = static_cast<double>(kappa);
+                        const bxh_run_status rs = slv.run(static_cast<double>(delta), static_cast<double>(theta),
+                                                          order, chunk, iter, static_cast<long>(p.w),
+                                                          static_cast<double>(kappa_max), kappa_inc);
+                        kappa = static_cast<Float>(rs.kappa);
+                        if (rs.stop == 1) {
+                            store_value(-push * p.pushing_iteration_limit - (iter + rs.sweeps - 1) - 1);
+                            break;
+                        }
+                        if (rs.stop == 2)
+                            break;
+                        iter += rs.sweeps;
+                        if (timeout()) {
+                            out_of_time = true;
+                            break;
+                        }
+                    }
+                    (void)out_of_time;
+                    continue;
+                }
                 for (int iter = 0; iter < p.pushing_iteration_limit; ++iter) {
                     slv.kappa[0] = static_cast<double>(kappa);
                     slv.sweep(static_cast<double>(delta), static_cast<double>(theta), false, 0.0, order);

@@ -172,6 +172,42 @@ int bxh_rmax(bxh_handle h);
  *   100 + g wide kernel (columns / row counts beyond the staged kernel: the XL
  *           shape), g workgroups per instance share every row */
 int bxh_kernel_form(bxh_handle h);
+/* Several sweeps of solver_functor's main loop (lib/src/itm-solver-common.hpp:
+ * 135-213) in ONE launch, for the handles bxh_run_supported() says yes to (the
+ * short-row kernel) and the row orders none / reversing / random_sorting:
+ *   for (i = first_i; ; ++i) { remaining = compute.run(kappa);
+ *       if (remaining == 0) stop (1);
+ *       if (remaining < best) { best = remaining; keep x; }
+ *       if (i > w_limit) kappa += kappa_inc[remaining];
+ *       if (kappa > kappa_max) stop (2);
+ *       if (sweeps == max_sweeps) stop (0); }
+ * kappa_inc[r] is the host's kappa_step * pow(r / m, alpha) evaluated in the
+ * handle's float type for r = 0 .. m (so the device adds exactly what the host
+ * would).  pi, x and the row list stay on chip between the sweeps; the status
+ * blocks are those behind the last sweep, row_updates / alg_bytes cover all. */
+typedef struct bxh_run_args
+{
+    const double* kappa;      /* [batch] kappa of the first sweep */
+    double delta, theta;
+    int order;
+    int max_sweeps, first_i, w_limit;
+    double kappa_max;
+    const double* kappa_inc;  /* [m + 1] */
+    const unsigned char* active;
+} bxh_run_args;
+typedef struct bxh_run_status
+{
+    int sweeps;         /* sweeps run */
+    int best_remaining; /* fewest violated rows behind a sweep of this launch (INT_MAX: feasible at once) */
+    int best_i;         /* ... its loop index */
+    int stop;           /* 0 max_sweeps, 1 no row violated, 2 kappa > kappa_max */
+    double kappa;       /* kappa behind the last sweep's update */
+} bxh_run_status;
+int bxh_run_supported(bxh_handle h);
+int bxh_run(bxh_handle h, const bxh_run_args* a, bxh_status* status_batch, bxh_run_status* run_batch);
+/* x behind the sweep best_remaining refers to (solver_functor::store_if_better) */
+int bxh_get_best_x(bxh_handle h, int inst, uint64_t* words);
+
 /* 1: compute_violated_constraints runs inside the sweep kernel (its bytes belong
  * to that kernel's roofline); 0: in launches of its own behind it (the wide
  * kernel with at most 32 instances: one pass over A for all of them) */

@@ -105,3 +105,102 @@ def test_narrow_baseline_shapes_many_instances(oracle, bxh, name, monkeypatch):
     monkeypatch.delenv("BXH_NARROW", raising=False)
     inst = synth.config_c1("int") if name == "c1" else synth.config_c3("int")
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=70, sweeps=4, push_at=(2,), expect_form=5)
+
+
+RUN_CASES = [
+    ("scp-real", lambda: synth.make_scp(60, 400, 0.06, "real", 311), 1, 1, 0),
+    ("spp-int-f32-reversing", lambda: synth.make_spp(40, 300, 0.06, "int", 312), 0, 0, 1),
+    ("pm1-random-order", lambda: synth.make_pm1(50, 250, 0.06, "real", 313), 1, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", RUN_CASES, ids=[c[0] for c in RUN_CASES])
+def test_run_of_many_sweeps_equals_single_sweeps(oracle, bxh, case):
+    """bxh_run -- solver_functor's loop (itm-solver-common.hpp:135-213) with up to
+    `max_sweeps` sweeps per launch, kappa moved on the device by the host's own
+    increments -- against the same loop driven sweep by sweep (one launch each,
+    the path every other test pins on the oracle): same number of sweeps, same
+    stop, same kappa, x, pi, P, engine; and the x kept for the sweep with the
+    fewest violated rows."""
+    _, maker, float_type, kind_unused, order = case
+    inst = maker()
+    F = np.float64 if float_type else np.float32
+    s0 = oracle.Solver(inst, float_type=float_type, sort_mode=1, cost_norm=4, seed=5)
+    cost, delta, theta = s0.cost(), s0.compute_delta(0.5), 0.5
+    kappa_step, kappa_max, alpha, w_limit = F(2e-3), F(0.6), F(1.0), 3
+    inc = np.array([float(F(kappa_step * F(np.power(F(r) / F(inst.m), alpha)))) for r in range(inst.m + 1)])
+    batch = 3
+
+    def fresh():
+        d = bxh.DeviceBatch(inst, cost, batch, float_type=float_type)
+        assert d.kernel_form == 5
+        for b in range(batch):
+            d.set_x(b, random_x(inst.n, 0.02 * b, 90 + b))
+            d.set_rng(b, 1000 + b)
+        d.order_init(order)
+        return d
+
+    from helpers import random_x, bits_equal  # noqa: F401  (used by fresh)
+    one, many = fresh(), fresh()
+    # sweep by sweep, per instance state on the host
+    kap = [F(0.01 * (b + 1)) for b in range(batch)]
+    done = [None] * batch
+    best = [(2 ** 31 - 1, None, None)] * batch
+    sweeps = [0] * batch
+    limit = 40
+    for i in range(limit):
+        act = np.array([done[b] is None for b in range(batch)], np.uint8)
+        if not act.any():
+            break
+        st = one.sweep(np.array([float(k) for k in kap]), delta, theta, order=order, active=act)
+        for b in range(batch):
+            if done[b] is not None:
+                continue
+            sweeps[b] += 1
+            rem = int(st["remaining"][b])
+            if rem == 0:
+                done[b] = 1
+                continue
+            if rem < best[b][0]:
+                best[b] = (rem, i, one.get_x(b))
+            if i > w_limit:
+                kap[b] = F(kap[b] + F(inc[rem]))
+            if kap[b] > kappa_max:
+                done[b] = 2
+    # the same in launches of 7 sweeps (each instance stops on its own; the
+    # others of the batch go on: a launch leaves a stopped instance alone next time)
+    kap2 = np.array([0.01 * (b + 1) for b in range(batch)])
+    kap2 = np.array([float(F(k)) for k in kap2])
+    done2, best2, sweeps2 = [None] * batch, [(2 ** 31 - 1, None, None)] * batch, [0] * batch
+    i0 = [0] * batch
+    while any(d is None and i0[b] < limit for b, d in enumerate(done2)):
+        for b in range(batch):  # (one instance per launch: their loop indices differ once one has stopped)
+            if done2[b] is not None or i0[b] >= limit:
+                continue
+            act = np.zeros(batch, np.uint8)
+            act[b] = 1
+            # run() takes no mask in this wrapper: use a one-instance view through kappa only
+            stt, rs = many.run_masked(kap2, delta, theta, order, min(7, limit - i0[b]), i0[b], w_limit,
+                                      float(kappa_max), inc, act)
+            r = rs[b]
+            sweeps2[b] += int(r["sweeps"])
+            if r["best_remaining"] < best2[b][0]:
+                best2[b] = (int(r["best_remaining"]), int(r["best_i"]), many.get_best_x(b))
+            kap2[b] = r["kappa"]
+            i0[b] += int(r["sweeps"])
+            if r["stop"] in (1, 2):
+                done2[b] = int(r["stop"])
+    for b in range(batch):
+        assert sweeps2[b] == sweeps[b], b
+        assert done2[b] == done[b], b
+        assert float(F(kap[b])) == kap2[b], b
+        assert np.array_equal(one.get_x(b), many.get_x(b)), b
+        assert bits_equal(one.get_pi(b), many.get_pi(b)), b
+        assert bits_equal(one.get_P(b), many.get_P(b)), b
+        assert one.get_rng(b) == many.get_rng(b), b
+        assert best2[b][0] == best[b][0] and best2[b][1] == best[b][1], b
+        if best[b][2] is not None:
+            assert np.array_equal(best[b][2], best2[b][2]), b
+    one.close()
+    many.close()
+
