@@ -566,6 +566,13 @@ def main():
 
     for k in range(args.warmup):
         wl.step(k)
+    if world > 1:
+        # the collectives of the exchange step once, untimed: the first all-reduce /
+        # broadcast of a process group sets its communicators up (seconds with RCCL)
+        from baryonyx_amd.dist import reduce_incumbent
+        reduce_incumbent(np.inf, np.zeros(dev.nwords, np.uint64), device="cpu" if share else "cuda")
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cpu" if share else "cuda"),
+                        op=dist.ReduceOp.MAX)
     barrier()
     dev.kernel_time(reset=True)
     st0 = dev.status()
