@@ -1211,8 +1211,8 @@ bxh_create(const bxh_problem* pb,
         HIP_TRY(h->wcnt.alloc(4 * B + 1));
         HIP_TRY(hipMemset(h->wcnt.p, 0, (4 * B + 1) * sizeof(unsigned)));
         HIP_TRY(h->vbuf.alloc(B * static_cast<size_t>(rmax)));
-        HIP_TRY(h->bkey.alloc(B * Gz * n2big));
-        HIP_TRY(h->bid.alloc(B * Gz * n2big));
+        HIP_TRY(h->bkey.alloc(B * (Gz + 2) * n2big));
+        HIP_TRY(h->bid.alloc(B * (Gz + 2) * n2big));
         HIP_TRY(h->vflag32.alloc(B * static_cast<size_t>(m)));
         if (batch <= 32 && !std::getenv("BXH_WIDE_OWN_SCAN"))
             HIP_TRY(h->xt.alloc(static_cast<size_t>(n)));
@@ -1234,6 +1234,7 @@ bxh_create(const bxh_problem* pb,
         wp.vflag32 = h->vflag32.p;
         wp.xt = h->xt.p;
         wp.skip_scan = h->xt.p ? 1 : 0;
+    wp.own_sort = std::getenv("BXH_WIDE_OWN_SORT") ? 1 : 0;
         const int wl = static_cast<int>(h->lds_bytes);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, wl));
@@ -1707,8 +1708,8 @@ bxh_create_device(const bxh_problem* pb,
     HIP_TRY(h->wcnt.alloc(4 * B + 1));
     HIP_TRY(hipMemsetAsync(h->wcnt.p, 0, (4 * B + 1) * sizeof(unsigned), s));
     HIP_TRY(h->vbuf.alloc(B * static_cast<size_t>(rmax)));
-    HIP_TRY(h->bkey.alloc(B * Gz * n2big));
-    HIP_TRY(h->bid.alloc(B * Gz * n2big));
+    HIP_TRY(h->bkey.alloc(B * (Gz + 2) * n2big));
+    HIP_TRY(h->bid.alloc(B * (Gz + 2) * n2big));
     HIP_TRY(h->vflag32.alloc(B * static_cast<size_t>(m)));
         if (batch <= 32 && !std::getenv("BXH_WIDE_OWN_SCAN"))
             HIP_TRY(h->xt.alloc(static_cast<size_t>(n)));
@@ -1733,6 +1734,7 @@ bxh_create_device(const bxh_problem* pb,
     wp.vflag32 = h->vflag32.p;
     wp.xt = h->xt.p;
     wp.skip_scan = h->xt.p ? 1 : 0;
+    wp.own_sort = std::getenv("BXH_WIDE_OWN_SORT") ? 1 : 0;
     const int wlb = static_cast<int>(h->lds_bytes);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, wlb));

@@ -757,16 +757,26 @@ rank_sort_small(const Float* val_by_id,
 {
     const int tid = threadIdx.x;
     unsigned long long mine = ~0ull;
-    if (tid < n) {
-        mine = order_key<Float>(val_by_id[tid], maximize);
-        key_tmp[tid] = mine;
+    const int n8 = (n + 7) & ~7; // (key_tmp holds whole 64-entry runs: the padding fits)
+    if (tid < n8) {
+        if (tid < n)
+            mine = order_key<Float>(val_by_id[tid], maximize);
+        key_tmp[tid] = mine; // padding: the largest key, behind every element
     }
     __syncthreads();
     if (tid < n) {
         int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const unsigned long long kj = key_tmp[j];
-            rank += (kj < mine) || (kj == mine && j < tid);
+        // eight keys per round trip to LDS (uniform addresses: broadcast reads)
+        for (int j0 = 0; j0 < n8; j0 += 8) {
+            ulonglong2 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                q[u] = reinterpret_cast<const ulonglong2*>(key_tmp + j0)[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rank += (q[u].x < mine) || (q[u].x == mine && j0 + 2 * u < tid);
+                rank += (q[u].y < mine) || (q[u].y == mine && j0 + 2 * u + 1 < tid);
+            }
         }
         key_out[rank] = mine;
         id_out[rank] = tid;

@@ -71,9 +71,10 @@ struct WideParams
     unsigned* wcnt;            // [batch][4] arrival counters, then [1] error word
     unsigned long long* vbuf;  // [batch][rmax] reduced costs of a row that is sorted
     unsigned long long* bkey;  // [batch][G][n2big] sort scratch of long rows
-    int* bid;                  // [batch][G][n2big]
+    int* bid;                  // [batch][G + 2][n2big] (copy G: sorted chunks, G + 1: the sorted row; shared)
     int* vflag32;              // [batch][m] violated flags of the end-of-sweep scan
     unsigned* xt;              // [n] x of all instances, one bit per instance (batch <= 32), or null
+    int own_sort;              // 1: a long tied row is sorted by every workgroup on its own (BXH_WIDE_OWN_SORT)
     int skip_scan;             // 1: the sweep kernel leaves compute_violated_constraints to
                                //    wide_flags_all_kernel (one pass over A for all instances)
 };
@@ -212,6 +213,143 @@ wide_sort_big(unsigned long long* gkey, int* gid, int n2, unsigned long long* lk
             store_chunk(c0);
         }
     }
+}
+
+__device__ inline bool
+wide_sync(unsigned* cnt, unsigned target, unsigned* err, int* dead_s);
+
+// The same order ("by key, then by row-local id") worked out by the G
+// workgroups of the instance together, every one a share: the row is cut into
+// chunks of C pairs (a power of two; chunk c is workgroup c % G's), each chunk is
+// sorted in LDS and published (ckey / cid, shared by the instance); then every
+// element's final position is its position in its own chunk plus, for every
+// other chunk -- staged in LDS in turn -- the number of pairs below it (a binary
+// search: the pairs are distinct), and it is written there (fkey / fid, shared).
+// Every workgroup then takes a copy of its own (okey / oid: the shuffle of the
+// tied runs permutes it).  Two meetings of the instance's workgroups at the
+// slow-row counter.  Returns false when a partner was lost.
+template<typename Float>
+__device__ inline bool
+wide_sort_coop(const unsigned long long* vbuf, int r, int n2, bool maximize, int grp, int G,
+               unsigned long long* ckey, int* cid, unsigned long long* fkey, int* fid,
+               unsigned long long* okey, int* oid, unsigned long long* lk, int* li, int C,
+               unsigned* cnt_sl, unsigned& nslow, unsigned* err, int* dead_s)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int NC = n2 / C;
+    constexpr int MAXU = 4; // C <= 4 * T
+    auto ld64 = [](const unsigned long long* p_) -> unsigned long long {
+        return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto ld32 = [](const int* p_) -> int {
+        return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // ---- own chunks: sorted in LDS, published ----------------------------------
+    for (int c = grp; c < NC; c += G) {
+        const int c0 = c * C;
+        for (int t = tid; t < C; t += T) {
+            const int i = c0 + t;
+            unsigned long long key = ~0ull;
+            if (i < r)
+                key = order_key<Float>((Float)__longlong_as_double((long long)ld64(&vbuf[i])), maximize);
+            lk[t] = key;
+            li[t] = i;
+        }
+        __syncthreads();
+        for (int k = 2; k <= C; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (C >> 1); t += T) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const bool asc = (i & k) == 0;
+                    const unsigned long long ka = lk[i], kb = lk[l];
+                    const int ia = li[i], ib = li[l];
+                    const bool gt = (ka > kb) || (ka == kb && ia > ib);
+                    if (gt == asc) {
+                        lk[i] = kb;
+                        li[i] = ib;
+                        lk[l] = ka;
+                        li[l] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        for (int t = tid; t < C; t += T) {
+            __hip_atomic_store(&ckey[c0 + t], lk[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cid[c0 + t], li[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    if (!wide_sync(cnt_sl, (unsigned)G * (nslow + 1u), err, dead_s))
+        return false;
+    ++nslow;
+    // ---- final positions of the own chunks' pairs ---------------------------------
+    for (int c = grp; c < NC; c += G) {
+        const int c0 = c * C;
+        unsigned long long mk[MAXU];
+        int mi[MAXU], rank[MAXU];
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+            const int t = tid + u * T;
+            mk[u] = ~0ull;
+            mi[u] = 0x7fffffff;
+            rank[u] = t;
+            if (t < C) {
+                mk[u] = ld64(&ckey[c0 + t]);
+                mi[u] = ld32(&cid[c0 + t]);
+            }
+        }
+        for (int x = 0; x < NC; ++x) {
+            if (x == c)
+                continue;
+            __syncthreads(); // (the chunk staged before has been searched by every thread)
+            for (int t = tid; t < C; t += T) {
+                lk[t] = ld64(&ckey[x * C + t]);
+                li[t] = ld32(&cid[x * C + t]);
+            }
+            __syncthreads();
+            int pos[MAXU];
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u)
+                pos[u] = 0;
+            for (int step = C >> 1; step > 0; step >>= 1) {
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u) {
+                    const int q = pos[u] + step - 1;
+                    const unsigned long long kq = lk[q];
+                    const int iq = li[q];
+                    if (kq < mk[u] || (kq == mk[u] && iq < mi[u]))
+                        pos[u] += step;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) {
+                const unsigned long long kq = lk[pos[u]];
+                const int iq = li[pos[u]];
+                if (kq < mk[u] || (kq == mk[u] && iq < mi[u]))
+                    pos[u] += 1;
+                rank[u] += pos[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u)
+            if (tid + u * T < C) {
+                __hip_atomic_store(&fkey[rank[u]], mk[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&fid[rank[u]], mi[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
+    if (!wide_sync(cnt_sl, (unsigned)G * (nslow + 1u), err, dead_s))
+        return false;
+    ++nslow;
+    // ---- a copy of the sorted row for this workgroup --------------------------------
+    for (int i = tid; i < n2; i += T) {
+        okey[i] = ld64(&fkey[i]);
+        oid[i] = ld32(&fid[i]);
+    }
+    __syncthreads();
+    // (the shared copies are written again by the next long row with a tie, behind
+    // that row's own meeting: every workgroup has taken its copy by then)
+    return true;
 }
 
 // std::shuffle of ONE run of equal keys (ids[0 .. L) in LDS) by all threads:
@@ -1566,31 +1704,51 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 // ---- a long row: sorted in global scratch (every workgroup its
                 // own copy), tied runs shuffled by one thread ------------------
                 const int n2 = next_pow2(r);
-                unsigned long long* bkey = wp.bkey + ((size_t)inst * G + grp) * (size_t)wp.n2big;
-                int* bid = wp.bid + ((size_t)inst * G + grp) * (size_t)wp.n2big;
-                for (int i = tid; i < n2; i += T) {
-                    unsigned long long key = ~0ull;
-                    if (i < r)
-                        key = order_key<Float>(
-                          (Float)__longlong_as_double((long long)__hip_atomic_load(
-                            &vbuf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)),
-                          maximize);
-                    bkey[i] = key;
-                    bid[i] = i;
-                }
-                __syncthreads();
+                unsigned long long* const bkey0 = wp.bkey + (size_t)inst * (G + 2) * (size_t)wp.n2big;
+                int* const bid0 = wp.bid + (size_t)inst * (G + 2) * (size_t)wp.n2big;
+                unsigned long long* bkey = bkey0 + (size_t)grp * (size_t)wp.n2big;
+                int* bid = bid0 + (size_t)grp * (size_t)wp.n2big;
                 // LDS scratch of this path: the pi window (refilled at the start of every
                 // tile set) and the staging slots (idle outside the column sums)
                 const int ring_bytes = wp.ring * (int)sizeof(Float);
                 unsigned long long* lk = (unsigned long long*)ring_s;
                 int* li = (int*)uni;
-                int C = 512;
-                while (C * 2 <= n2 && C * 2 * 8 <= ring_bytes && C * 2 * 4 <= lp.union_bytes)
-                    C *= 2;
-                if (C * 8 <= ring_bytes && C * 4 <= lp.union_bytes && C <= n2)
-                    wide_sort_big(bkey, bid, n2, lk, li, C);
-                else
-                    bitonic_sort(bkey, bid, n2);
+                // the workgroups of the instance sort a share each (chunks of Cc pairs,
+                // about one per workgroup) where LDS holds such a chunk ...
+                int Cc = next_pow2((n2 + G - 1) / G);
+                while (Cc > 64 && (Cc > 4 * T || Cc * 8 > ring_bytes || Cc * 4 > lp.union_bytes))
+                    Cc >>= 1;
+                const bool coop = G > 1 && !wp.own_sort && Cc >= 64 && Cc <= n2 && Cc <= 4 * T &&
+                                  Cc * 8 <= ring_bytes && Cc * 4 <= lp.union_bytes;
+                if (coop) {
+                    if (!wide_sort_coop<Float>(vbuf, r, n2, maximize, grp, G, bkey0 + (size_t)G * wp.n2big,
+                                               bid0 + (size_t)G * wp.n2big, bkey0 + (size_t)(G + 1) * wp.n2big,
+                                               bid0 + (size_t)(G + 1) * wp.n2big, bkey, bid, lk, li, Cc, cnt_sl,
+                                               nslow, err_word, misc_s + WM_DEAD)) {
+                        dead = true;
+                        break;
+                    }
+                } else {
+                    // ... or every workgroup the whole row, in its own copy
+                    for (int i = tid; i < n2; i += T) {
+                        unsigned long long key = ~0ull;
+                        if (i < r)
+                            key = order_key<Float>(
+                              (Float)__longlong_as_double((long long)__hip_atomic_load(
+                                &vbuf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)),
+                              maximize);
+                        bkey[i] = key;
+                        bid[i] = i;
+                    }
+                    __syncthreads();
+                    int C = 512;
+                    while (C * 2 <= n2 && C * 2 * 8 <= ring_bytes && C * 2 * 4 <= lp.union_bytes)
+                        C *= 2;
+                    if (C * 8 <= ring_bytes && C * 4 <= lp.union_bytes && C <= n2)
+                        wide_sort_big(bkey, bid, n2, lk, li, C);
+                    else
+                        bitonic_sort(bkey, bid, n2);
+                }
                 for (int i = tid; i + 1 < r; i += T)
                     if (bkey[i] == bkey[i + 1])
                         misc_s[MS_TIE] = 1;

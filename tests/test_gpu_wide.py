@@ -42,12 +42,21 @@ def test_wide_kernel_edge_shapes(oracle, bxh, case, groups, monkeypatch):
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p, sweeps=8, push_at=(3, 6))
 
 
-def test_wide_kernel_long_tied_rows(oracle, bxh, monkeypatch):
-    """Rows of ~3000 elements with integer costs: every row of the first sweep
-    holds runs of equal reduced costs (the long-row sort and its shuffles)."""
-    monkeypatch.setenv("BXH_GROUPS", "w4")
-    inst = synth.make_scp(40, 30000, 0.1, "int", 95)
-    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=3, push_at=(2,), expect_form=104)
+@pytest.mark.parametrize("groups,cols,own", [("w4", 30000, False), ("w3", 30000, False), ("w2", 70000, False),
+                                             ("w4", 30000, True)],
+                         ids=["w4-chunk-each", "w3-one-idle", "w2-two-chunks-each", "w4-own-sort"])
+def test_wide_kernel_long_tied_rows(oracle, bxh, groups, cols, own, monkeypatch):
+    """Rows of ~3000 (7000) elements with integer costs: every row of the first
+    sweep holds runs of equal reduced costs (the long-row sort and its shuffles).
+    The workgroups of an instance sort the row together -- a chunk of 1024 pairs
+    each (4 workgroups), 2 chunks of 2048 for 3 workgroups (one has none), 4 chunks
+    of 2048 for 2 workgroups -- or (BXH_WIDE_OWN_SORT) every one the whole row."""
+    monkeypatch.setenv("BXH_GROUPS", groups)
+    if own:
+        monkeypatch.setenv("BXH_WIDE_OWN_SORT", "1")
+    inst = synth.make_scp(40, cols, 0.1, "int", 95)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=3, push_at=(2,),
+             expect_form=100 + int(groups[1:]))
 
 
 @pytest.mark.parametrize("ncost", [2, 6, 40], ids=["runs-of-1500", "runs-of-500", "runs-of-75"])
