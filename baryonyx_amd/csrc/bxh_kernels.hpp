@@ -764,9 +764,12 @@ rank_sort_small(const Float* val_by_id,
         key_tmp[tid] = mine; // padding: the largest key, behind every element
     }
     __syncthreads();
+    // eight keys per round trip to LDS (uniform addresses: broadcast reads).
+    // First by the keys alone (one compare per pair): without two equal keys the
+    // counts are the ranks; equal keys land on one position, which the loser
+    // of the two stores sees -- the row then counts again with the ids.
+    int rank = 0;
     if (tid < n) {
-        int rank = 0;
-        // eight keys per round trip to LDS (uniform addresses: broadcast reads)
         for (int j0 = 0; j0 < n8; j0 += 8) {
             ulonglong2 q[4];
 #pragma unroll
@@ -774,14 +777,34 @@ rank_sort_small(const Float* val_by_id,
                 q[u] = reinterpret_cast<const ulonglong2*>(key_tmp + j0)[u];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                rank += (q[u].x < mine) || (q[u].x == mine && j0 + 2 * u < tid);
-                rank += (q[u].y < mine) || (q[u].y == mine && j0 + 2 * u + 1 < tid);
+                rank += q[u].x < mine;
+                rank += q[u].y < mine;
             }
         }
         key_out[rank] = mine;
         id_out[rank] = tid;
     }
     __syncthreads();
+    const bool lost = tid < n && id_out[rank] != tid;
+    if (__syncthreads_or(lost)) {
+        if (tid < n) {
+            rank = 0;
+            for (int j0 = 0; j0 < n8; j0 += 8) {
+                ulonglong2 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    q[u] = reinterpret_cast<const ulonglong2*>(key_tmp + j0)[u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    rank += (q[u].x < mine) || (q[u].x == mine && j0 + 2 * u < tid);
+                    rank += (q[u].y < mine) || (q[u].y == mine && j0 + 2 * u + 1 < tid);
+                }
+            }
+            key_out[rank] = mine;
+            id_out[rank] = tid;
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1888,9 +1911,12 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         int k, rs, re, zk, bmin, bmax;
         double rbytes;
     };
-    auto row_of = [&](int it_) -> RowZ {
+    // (the row's number is fetched a row before its scalars: neither load is waited
+    // for in the row that issues it)
+    auto row_id = [&](int it_) -> int { return (ord == 1) ? vlist[nrows - 1 - it_] : vlist[it_]; };
+    auto row_of = [&](int k_) -> RowZ {
         RowZ x;
-        x.k = (ord == 1) ? vlist[nrows - 1 - it_] : vlist[it_];
+        x.k = k_;
         x.rs = pb.row_ptr[x.k];
         x.re = pb.row_ptr[x.k + 1];
         x.zk = pb.zkind[x.k];
@@ -1901,14 +1927,17 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     };
     RowZ nxt = { 0, 0, 0, 0, 0, 0, 0.0 };
     if (nrows > 0)
-        nxt = row_of(0);
+        nxt = row_of(row_id(0));
+    int k_ahead = nrows > 1 ? row_id(1) : 0; // the row after `nxt`
     bool pre_ok = false; // the lane's element descriptor of the next row is in registers
     int2 pre_cs = make_int2(0, 0);
     int pre_j = 0, pre_pe = 0, pre_f = 0;
     for (int it = 0; it < nrows; ++it) {
         const RowZ cur = nxt;
         if (it + 1 < nrows)
-            nxt = row_of(it + 1);
+            nxt = row_of(k_ahead);
+        if (it + 2 < nrows)
+            k_ahead = row_id(it + 2);
         const int k = cur.k;
         const int rs = cur.rs;
         const int r = cur.re - cur.rs;
