@@ -323,6 +323,21 @@ dpp_u64(unsigned long long v)
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 
+// quad_perm broadcast inside lane pairs: 0xA0 = [0,0,2,2] (every lane takes the even
+// lane's value), 0xF5 = [1,1,3,3] (the odd lane's)
+template<int CTRL, typename Float>
+__device__ inline Float
+pair_bcast(Float v)
+{
+    if constexpr (sizeof(Float) == 8) {
+        const unsigned long long r = dpp_u64<CTRL>((unsigned long long)__double_as_longlong((double)v));
+        return (Float)__longlong_as_double((long long)r);
+    } else {
+        const int r = __builtin_amdgcn_update_dpp(0, __float_as_int((float)v), CTRL, 0xf, 0xf, false);
+        return (Float)__int_as_float(r);
+    }
+}
+
 #define BXH_WAVE_REDUCE(V, OP)                                                 \
     do {                                                                       \
         unsigned long long t_;                                                 \
@@ -3048,20 +3063,27 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    // lanes 0-15 add the P entries and lanes 16-31 the pi entries of one
-    // staged column each, strictly in CSC order (as the lock-step kernel);
-    // returns the lane's sum and leaves the decayed own entry in *dec_out
-    // (row chain: a column loaded before the previous row's affect first takes
-    // that row's new entry, patch[t] = the entry's index in the previous row)
+    // Two lanes per staged column and kind: lanes 0-31 add the P entries, lanes
+    // 32-63 the pi entries, lane pair (2u, 2u + 1) of each half column u's --
+    // strictly in CSC order: of every 16-entry piece the even lane holds
+    // entries 0-7 and the odd lane entries 8-15 (all read from LDS at once: half
+    // as many LDS instructions per wave as with one lane per column and kind);
+    // the running sum then goes even lane -> odd lane -> even lane of the next
+    // piece (a DPP move inside the pair), so that every addition happens in the
+    // order and with the operands of the scalar loop.  Returns the lane's sum
+    // (both lanes of a pair hold it) and leaves the decayed own entry in dec_out
+    // (even P lanes).  (row chain: a column loaded before the previous row's affect
+    // first takes that row's new entry, patch[t] = the entry's index in the
+    // previous row)
     auto sum_m = [&](const int2* cs_r, const int* pe_r, const short* map, int cnt_, int chunk_,
                      int& l_out, Float& dec_out, const short2* patch = nullptr,
                      bool direct = false) -> Float {
-        const int lane5 = lane & 31;
-        const int u = lane5 & (CW - 1);
-        const bool is_pi = lane5 >= CW;
+        const int u = (lane & 31) >> 1;
+        const int sub = lane & 1;
+        const bool is_pi = lane >= 32;
         const int t = chunk_ * CW + u;
         const int tt = min(t, cnt_ - 1);
-        const int l = (lane < 32 && t < cnt_) ? (int)map[tt] : -1;
+        const int l = t < cnt_ ? (int)map[tt] : -1;
         const int2 csd = cs_r[tt];
         const int ped = pe_r[tt];
         l_out = l;
@@ -3069,7 +3091,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         if (l >= 0) {
             const int2 cs = direct ? csd : cs_r[l];
             const int cpad = cs.y & 0xffff;
-            if (!is_pi) { // P[e] *= theta for this row's entry
+            if (!is_pi && sub == 0) { // P[e] *= theta for this row's entry
                 if (patch) {
                     const short2 pp = patch[t];
                     if (pp.x >= 0)
@@ -3080,15 +3102,18 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 *pk = dec;
                 dec_out = dec;
             }
-            const Float2* sp2 = reinterpret_cast<const Float2*>(wst_p + u * SP);
-            const uint2* si2 = reinterpret_cast<const uint2*>(wst_i + u * SI);
-            // the row indices travel one batch of 16 ahead of the entries: the
-            // pi lanes then wait for one LDS round trip per batch, not two
-            unsigned sgn[8]; // 16 packed 16-bit indices of the next batch
+            // (LDS operations of one wave execute in order: the reads below see the
+            // patched and decayed entry; the compiler must not move them up)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const Float2* sp2 = reinterpret_cast<const Float2*>(wst_p + u * SP) + 4 * sub;
+            const uint2* si2 = reinterpret_cast<const uint2*>(wst_i + u * SI) + 2 * sub;
+            // the row indices travel one piece ahead of the entries: the pi lanes
+            // then wait for one LDS round trip per piece, not two
+            unsigned sgn[4]; // 8 packed 16-bit indices of the next piece (this lane's half)
             auto read_idx = [&](int i0_) {
                 if (is_pi || PM1) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
+                    for (int b = 0; b < 2; ++b) {
                         const uint2 w = si2[(i0_ >> 2) + b];
                         sgn[2 * b] = w.x;
                         sgn[2 * b + 1] = w.y;
@@ -3097,20 +3122,20 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             };
             read_idx(0);
             for (int i0 = 0; i0 < cpad; i0 += 16) {
-                Float v[16];
-                unsigned sg[8];
+                Float v[8];
+                unsigned sg[4];
 #pragma unroll
-                for (int b = 0; b < 8; ++b)
+                for (int b = 0; b < 4; ++b)
                     sg[b] = sgn[b];
                 if (is_pi) {
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) {
+                    for (int b = 0; b < 4; ++b) {
                         v[2 * b] = pi_s[sg[b] & 0x7fff];
                         v[2 * b + 1] = pi_s[(sg[b] >> 16) & 0x7fff];
                     }
                 } else {
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) {
+                    for (int b = 0; b < 4; ++b) {
                         const Float2 w = sp2[(i0 >> 1) + b];
                         v[2 * b] = w.x;
                         v[2 * b + 1] = w.y;
@@ -3118,15 +3143,24 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
                 if (i0 + 16 < cpad)
                     read_idx(i0 + 16);
+                if (PM1) {
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    Float term = v[b];
-                    if (PM1) {
+                    for (int b = 0; b < 8; ++b) {
                         const unsigned neg = (sg[b >> 1] >> ((b & 1) ? 31 : 15)) & 1u;
-                        term = neg ? -term : term;
+                        v[b] = neg ? -v[b] : v[b];
                     }
-                    acc += term;
                 }
+                // entries 0-7 (the even lane's), then 8-15 (the odd lane's)
+                Float a = acc;
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    a += v[b];
+                acc = pair_bcast<0xA0>(a); // both lanes: the even lane's sum
+                a = acc;
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    a += v[b];
+                acc = pair_bcast<0xF5>(a); // both lanes: the odd lane's sum
             }
         }
         return acc;
@@ -3237,10 +3271,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     BXH_PROD_STAMP(7);
                     int l;
                     Float dec;
-                    const Float cst = cost_s[min(chunk * CW + (lane & (CW - 1)), r - 1)];
+                    const Float cst = cost_s[min(chunk * CW + ((lane & 31) >> 1), r - 1)];
                     const Float acc = sum_m(cs_s, pe_s, emap, r, chunk, l, dec, nullptr, true);
-                    const Float spi = __shfl_down(acc, 16); // the pi lane of the same column
-                    if (l >= 0 && (lane & 31) < CW) {
+                    const Float spi = __shfl_down(acc, 32); // the pi lanes of the same column
+                    if (l >= 0 && lane < 32 && (lane & 1) == 0) {
                         Float v = cst - spi - acc;
                         if (PM1 && pb.fac_csr[rs + l] < 0)
                             v = -v;
@@ -3435,8 +3469,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     int l;
                     Float dec = 0;
                     const Float acc = sum_m(cs_s, pe_s, lmap, nl, chunk, l, dec, lpatch);
-                    const Float spi = __shfl_down(acc, 16); // the pi lane of the same column
-                    if (l >= 0 && (lane & 31) < CW) {
+                    const Float spi = __shfl_down(acc, 32); // the pi lanes of the same column
+                    if (l >= 0 && lane < 32 && (lane & 1) == 0) {
                         const Float cj = cost_s[l]; // (linear objective: the host checks)
                         Float v = cj - spi - acc;
                         if (PM1 && pb.fac_csr[rs + l] < 0)
