@@ -3091,6 +3091,23 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         if (l >= 0) {
             const int2 cs = direct ? csd : cs_r[l];
             const int cpad = cs.y & 0xffff;
+            const Float2* sp2 = reinterpret_cast<const Float2*>(wst_p + u * SP) + 4 * sub;
+            const uint2* si2 = reinterpret_cast<const uint2*>(wst_i + u * SI) + 2 * sub;
+            // the row indices travel one piece ahead of the entries: the pi lanes
+            // then wait for one LDS round trip per piece, not two (the first piece's
+            // are asked for in front of the decay: nothing changes them)
+            unsigned sgn[4]; // 8 packed 16-bit indices of the next piece (this lane's half)
+            auto read_idx = [&](int i0_) {
+                if (is_pi || PM1) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const uint2 w = si2[(i0_ >> 2) + b];
+                        sgn[2 * b] = w.x;
+                        sgn[2 * b + 1] = w.y;
+                    }
+                }
+            };
+            read_idx(0);
             if (!is_pi && sub == 0) { // P[e] *= theta for this row's entry
                 if (patch) {
                     const short2 pp = patch[t];
@@ -3105,22 +3122,6 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             // (LDS operations of one wave execute in order: the reads below see the
             // patched and decayed entry; the compiler must not move them up)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const Float2* sp2 = reinterpret_cast<const Float2*>(wst_p + u * SP) + 4 * sub;
-            const uint2* si2 = reinterpret_cast<const uint2*>(wst_i + u * SI) + 2 * sub;
-            // the row indices travel one piece ahead of the entries: the pi lanes
-            // then wait for one LDS round trip per piece, not two
-            unsigned sgn[4]; // 8 packed 16-bit indices of the next piece (this lane's half)
-            auto read_idx = [&](int i0_) {
-                if (is_pi || PM1) {
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const uint2 w = si2[(i0_ >> 2) + b];
-                        sgn[2 * b] = w.x;
-                        sgn[2 * b + 1] = w.y;
-                    }
-                }
-            };
-            read_idx(0);
             for (int i0 = 0; i0 < cpad; i0 += 16) {
                 Float v[8];
                 unsigned sg[4];
