@@ -175,6 +175,21 @@ struct Prof
 #define BXH_BARRIER(id) __syncthreads()
 #endif
 
+// Timeline build (-DBXH_TIMELINE, tools/debug/chain_timeline.py): lane 0 of every wave of
+// the row chain of instance 0 writes the shader clock at 16 points of rows 200..207 into
+// the profile buffer ([row][wave][point]).  Not for any other use.
+#ifdef BXH_TIMELINE
+#define BXH_TL(p_)                                                             \
+    do {                                                                       \
+        if (PIPE && grp == 0 && inst == 0 && it >= 200 && it < 208 && (tid & 63) == 0) \
+            st.prof[((it - 200) * 8 + (tid >> 6)) * 16 + (p_)] = (unsigned long long)clock64(); \
+    } while (0)
+#else
+#define BXH_TL(p_)                                                             \
+    do {                                                                       \
+    } while (0)
+#endif
+
 struct DevSweep
 {
     const double* kappa; // [batch]
@@ -3411,6 +3426,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         const Float* cost_s = cost_b + cur * RO;
         const int* oidx_s = oidx_b + cur * RO;
         const short* loc_s = loc_b + cur * pb.rmax;
+        BXH_TL(0);
 
         // ---- pipelined sweep, row chain: only the late columns are summed
         // here; the producers' values and the row's own P entries are loaded
@@ -3440,17 +3456,30 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             const int nl = misc_s[MS_LCNT + cur];
             const int nlc = (nl + CW - 1) / CW;
             const int* lnp = lnp_b + cur * LNPW;
+            // the producers' values and the own P entries of this thread's row entries.
+            // A staging wave asks for them BEHIND the staging of its late chunk: staging
+            // waits for the chunk's loads (issued a row ago), and the wait counter of a
+            // wave is in order -- asked for in front of it, these loads (a round trip to
+            // the producers' stores) would be waited for there, before the sums, instead
+            // of travelling under them (3 000 of a row's 21 000 cycles, found with the
+            // timeline build).
+            auto ask_values = [&]() {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int l = gl[s2];
-                if (l < r && !lflag[l]) {
-                    gP[s2] = P[pe_s[l]];
-                    gG[s2] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, roff + (unsigned)l * 16u, 0, 16);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int l = gl[s2];
+                    if (l < r && !lflag[l]) {
+                        gP[s2] = P[pe_s[l]];
+                        gG[s2] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, roff + (unsigned)l * 16u, 0, 16);
+                    }
                 }
-            }
+            };
+            if (wave >= SW || wave >= nlc)
+                ask_values();
             BXH_STAMP(13);
+            BXH_TL(1);
             if (wave >= SW && it + 1 < nrows)
                 classify_c(x1.re - x1.rs, cur ^ 1, it + 2, r, tid - SW * 64, T - SW * 64, x1.rs);
+            BXH_TL(2);
             if (wave < SW) {
                 // (the wave's first late chunk was loaded during the previous
                 // row, behind its barrier 1; what that row's affect changed
@@ -3461,6 +3490,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     npm = __builtin_amdgcn_readfirstlane(lnp[chunk]);
                 while (chunk < nlc) {
                     stage_m(lmap, nl, chunk, npm);
+                    if (chunk == wave)
+                        ask_values();
                     const int cn = chunk + SW;
                     int npn = 0;
                     if (cn < nlc) {
@@ -3488,6 +3519,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
             }
         }
+        BXH_TL(3);
         // ---- this row's first loads, then the next row's descriptor ---------
         const int nchunks = (ro + CW - 1) / CW;
         int chunk = wave;
@@ -3723,6 +3755,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         if (!PIPE && it + 1 < nrows)
             fetch_consts(x1.k);
         BXH_STAMP(1);
+        BXH_TL(4);
         if (MW) {
             // The waves that stored do not poll: a wave's loads would also
             // wait for the acknowledgement of its own write-through stores
@@ -3763,7 +3796,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             reinterpret_cast<uint4*>(htab)[i] = make_uint4(0u, 0u, 0u, 0u);
         if (PIPE) // what this thread stored to P in the previous row has arrived (a thread
             __builtin_amdgcn_s_waitcnt(0x0f70); // without a load of its own would not wait)
+        BXH_TL(5);
         BXH_BARRIER(1);
+        BXH_TL(6);
         if (PIPE) {
             // this buffer's late list is used up: empty it for the row after the next
             if (tid < LNPW)
@@ -3793,6 +3828,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         if (it + 1 < nrows)
             fill_loc(x1, cur ^ 1);
         BXH_STAMP(3);
+        BXH_TL(7);
 
         // ---- selection without sorting (rows with no two equal reduced
         // costs whose select_variables / affect only need the extreme order
@@ -3890,8 +3926,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
             }
             BXH_STAMP(8);
+            BXH_TL(8);
             BXH_BARRIER(2);
             BXH_STAMP(9);
+            BXH_TL(9);
             // Every wave then runs the same, wave-uniform selection logic on
             // scalar registers: no second barrier, no broadcast through LDS.
             // All threads keep identical copies of the engine state (re-read
@@ -4018,6 +4056,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
             }
             BXH_STAMP(10);
+            BXH_TL(10);
         }
         if (fast) {
             BXH_STAMP(1);
@@ -4067,8 +4106,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
             }
             BXH_STAMP(12);
+            BXH_TL(11);
             BXH_BARRIER(3);
             BXH_STAMP(6);
+            BXH_TL(12);
             continue;
         }
 
