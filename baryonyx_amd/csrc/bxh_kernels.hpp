@@ -3490,6 +3490,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     npm = __builtin_amdgcn_readfirstlane(lnp[chunk]);
                 while (chunk < nlc) {
                     stage_m(lmap, nl, chunk, npm);
+                    BXH_TL(13);
+#ifdef BXH_TIMELINE
+                    if (inst == 0 && it >= 200 && it < 208 && lane == 0) // (pieces, late columns of the row)
+                        st.prof[((it - 200) * 8 + wave) * 16 + 14] = (unsigned long long)(npm * 1000 + nl);
+#endif
                     if (chunk == wave)
                         ask_values();
                     const int cn = chunk + SW;
@@ -3501,6 +3506,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     int l;
                     Float dec = 0;
                     const Float acc = sum_m(cs_s, pe_s, lmap, nl, chunk, l, dec, lpatch);
+                    BXH_TL(15);
                     const Float spi = __shfl_down(acc, 32); // the pi lanes of the same column
                     if (l >= 0 && lane < 32 && (lane & 1) == 0) {
                         const Float cj = cost_s[l]; // (linear objective: the host checks)

@@ -40,6 +40,16 @@ for step in range(4):
     print("  phase                         " + " ".join(f"w{w:<5d}" for w in range(8)))
     for p in range(1, NP):
         print(f"  {names[p]:28s}  " + " ".join(f"{cyc[:, w, p - 1].mean():6.0f}" for w in range(8)))
+    # (a row with more than 64 late columns gives its first staging wave a second chunk: the
+    # points 13 / 15 then belong to that second pass -- in the C2 instance 1.5 % of the rows,
+    # three of the eight sampled here)
+    for nm, a, b in (("  late: staged", 2, 13), ("  late: summed (+ values asked)", 13, 15), ("  late: written", 15, 3)):
+        dd = tl[:, :4, b] - tl[:, :4, a]
+        print(f"  {nm:28s}  " + " ".join(f"{np.median(dd[:, w]):6.0f}" for w in range(4)) + "   (medians)")
+    d = tl[:, :4, 13] - tl[:, :4, 2]
+    print("  late chunk staged (cycles from the top of the late block), rows x staging waves:")
+    for rr in range(8):
+        print("     " + " ".join(f"{d[rr, w]:6d} (pieces {tl[rr, w, 14] // 1000}, late {tl[rr, w, 14] % 1000})" for w in range(4)))
     for b, p in (("B1", 5), ("B2", 8), ("B3", 11)):
         arr = tl[:, :, p] - tl[:, :, p].min(axis=1, keepdims=True)
         print(f"  arrival at {b} (cycles after the first wave): " + " ".join(f"{arr[:, w].mean():6.0f}" for w in range(8)))
