@@ -184,8 +184,17 @@ struct Prof
         if (PIPE && grp == 0 && inst == 0 && it >= 200 && it < 208 && (tid & 63) == 0) \
             st.prof[((it - 200) * 8 + (tid >> 6)) * 16 + (p_)] = (unsigned long long)clock64(); \
     } while (0)
+// the same for the first producer of instance 0 (second half of the profile buffer)
+#define BXH_TLP(p_)                                                            \
+    do {                                                                       \
+        if (PIPE && grp == 1 && inst == 0 && it >= 200 && it < 208 && (tid & 63) == 0) \
+            st.prof[1024 + ((it - 200) * 8 + (tid >> 6)) * 16 + (p_)] = (unsigned long long)clock64(); \
+    } while (0)
 #else
 #define BXH_TL(p_)                                                             \
+    do {                                                                       \
+    } while (0)
+#define BXH_TLP(p_)                                                            \
     do {                                                                       \
     } while (0)
 #endif
@@ -3236,12 +3245,15 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             const int* pe_s = pe_b + cur * RO;
             const Float* cost_s = cost_b + cur * RO;
             const short* emap = map_b + cur * pb.rmax;
+            BXH_TLP(0);
             __syncthreads(); // every wave is through with row it - 1 (the other descriptor buffer)
             BXH_PROD_STAMP(0);
+            BXH_TLP(1);
             if (it + 1 < nrows) {
                 store_desc(x1, cur ^ 1);
                 classify_p(x1.re - x1.rs, cur ^ 1, q + 1);
                 BXH_PROD_STAMP(1);
+                BXH_TLP(2);
                 // position q + 1 reads P once the rows up to position q - D are
                 // finished: their pi.  (The columns still being summed for row
                 // it hold none of them.)
@@ -3254,8 +3266,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
             }
             BXH_PROD_STAMP(2);
+            BXH_TLP(3);
             __syncthreads(); // the next row's map and descriptor; the message has been seen
             BXH_PROD_STAMP(3);
+            BXH_TLP(4);
             const int nchunks = (r + CW - 1) / CW;
             const unsigned roff = (unsigned)(q % PIPE_RING) * (unsigned)pb.rmax * 16u;
             const unsigned tagq = tag_of(q);
@@ -3272,9 +3286,12 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     first_chunk(x1, cur ^ 1);
                 }
                 int npm = chunk < nchunks ? chunk_pieces(cs_s, chunk) : 0;
+                int tlj = 0; // (timeline: the wave's first / second chunk of the row)
+                (void)tlj;
                 while (chunk < nchunks) {
                     stage_m(emap, r, chunk, npm);
                     BXH_PROD_STAMP(6);
+                    BXH_TLP(5 + 4 * tlj);
                     i += SW;
                     const int cn = me + np_ * i;
                     int npn = 0;
@@ -3285,10 +3302,12 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         first_chunk(x1, cur ^ 1);
                     }
                     BXH_PROD_STAMP(7);
+                    BXH_TLP(6 + 4 * tlj);
                     int l;
                     Float dec;
                     const Float cst = cost_s[min(chunk * CW + ((lane & 31) >> 1), r - 1)];
                     const Float acc = sum_m(cs_s, pe_s, emap, r, chunk, l, dec, nullptr, true);
+                    BXH_TLP(7 + 4 * tlj);
                     const Float spi = __shfl_down(acc, 32); // the pi lanes of the same column
                     if (l >= 0 && lane < 32 && (lane & 1) == 0) {
                         Float v = cst - spi - acc;
@@ -3299,11 +3318,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    BXH_TLP(8 + 4 * tlj);
+                    tlj = tlj < 1 ? tlj + 1 : 1;
                     chunk = cn;
                     npm = npn;
                 }
             }
             BXH_PROD_STAMP(4);
+            BXH_TLP(13);
             if (it + 2 < nrows) {
                 fetch_desc(x2);
                 if (it + 3 < nrows) {
@@ -3313,6 +3335,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
             }
             BXH_PROD_STAMP(5);
+            BXH_TLP(14);
         }
 #ifdef BXH_PROFILE
         if (tid == 0 && grp == 1)

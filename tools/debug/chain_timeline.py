@@ -53,3 +53,22 @@ for step in range(4):
     for b, p in (("B1", 5), ("B2", 8), ("B3", 11)):
         arr = tl[:, :, p] - tl[:, :, p].min(axis=1, keepdims=True)
         print(f"  arrival at {b} (cycles after the first wave): " + " ".join(f"{arr[:, w].mean():6.0f}" for w in range(8)))
+
+    # ---- the first producer of the same instance (points 0..14, two chunks at most) ----
+    pt = t.reshape(-1)[1024:2048].reshape(8, 8, 16).astype(np.int64)
+    pn = ["top", "barrier A", "descriptor + classify", "message (thread 0 polls)", "barrier B",
+          "chunk 1 staged", "chunk 1 next loads issued", "chunk 1 summed", "chunk 1 stored",
+          "chunk 2 staged", "chunk 2 next loads issued", "chunk 2 summed", "chunk 2 stored",
+          "chunk loop left", "descriptor of row + 2 asked"]
+    prow = pt[1:, 0, 0] - pt[:-1, 0, 0]
+    print("  producer 1, cycles per row (wave 0, top to top):", prow.tolist())
+    print("  producer phase                " + " ".join(f"w{w:<5d}" for w in range(8)))
+    for p in range(1, 15):
+        cells = []
+        for w in range(8):
+            a, b = pt[:, w, p], pt[:, w, p - 1]
+            if p in (9, 13):  # behind an optional second chunk: from whatever came last
+                b = np.where(pt[:, w, 12] > pt[:, w, 8], pt[:, w, 12], pt[:, w, 8]) if p == 13 else pt[:, w, 8]
+            ok = (a > 0) & (b > 0) & (a >= b)
+            cells.append(f"{(a - b)[ok].mean():6.0f}" if ok.any() else "     -")
+        print(f"  {pn[p]:28s}  " + " ".join(cells))
