@@ -3618,7 +3618,87 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 }
                 BXH_STAMP(13);
 
-                {
+                if (!dual) {
+                    // two lanes per column and kind (see sum_m): lanes 0-31 the P entries,
+                    // lanes 32-63 the pi entries, the even lane of a pair entries 0-7 of
+                    // every piece, the odd lane entries 8-15; same order of additions
+                    const int u = (lane & 31) >> 1;
+                    const int sub = lane & 1;
+                    const bool is_pi = lane >= 32;
+                    const int t = chunk * CW + u;
+                    if (t < ro) {
+                        const int2 cs = cs_s[t];
+                        const int cpad = cs.y & 0xffff;
+                        const Float2* sp2 = reinterpret_cast<const Float2*>(wst_p + u * SP) + 4 * sub;
+                        const uint2* si2 = reinterpret_cast<const uint2*>(wst_i + u * SI) + 2 * sub;
+                        unsigned sgn[4];
+                        auto read_idx = [&](int i0_) {
+                            if (is_pi || PM1) {
+#pragma unroll
+                                for (int b = 0; b < 2; ++b) {
+                                    const uint2 w = si2[(i0_ >> 2) + b];
+                                    sgn[2 * b] = w.x;
+                                    sgn[2 * b + 1] = w.y;
+                                }
+                            }
+                        };
+                        read_idx(0);
+                        if (!is_pi && sub == 0) { // P[e] *= theta for this row's entry
+                            Float* pk = wst_p + u * SP + (pe_s[t] - cs.x);
+                            const Float dec = *pk * theta; // (stored to HBM by affect)
+                            *pk = dec;
+                            pown_s[t] = dec;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        Float acc = 0;
+                        for (int i0 = 0; i0 < cpad; i0 += 16) {
+                            Float v[8];
+                            unsigned sg[4];
+#pragma unroll
+                            for (int b = 0; b < 4; ++b)
+                                sg[b] = sgn[b];
+                            if (is_pi) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    v[2 * b] = pi_s[sg[b] & 0x7fff];
+                                    v[2 * b + 1] = pi_s[(sg[b] >> 16) & 0x7fff];
+                                }
+                            } else {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const Float2 w = sp2[(i0 >> 1) + b];
+                                    v[2 * b] = w.x;
+                                    v[2 * b + 1] = w.y;
+                                }
+                            }
+                            if (i0 + 16 < cpad)
+                                read_idx(i0 + 16);
+                            if (PM1) {
+#pragma unroll
+                                for (int b = 0; b < 8; ++b) {
+                                    const unsigned neg = (sg[b >> 1] >> ((b & 1) ? 31 : 15)) & 1u;
+                                    v[b] = neg ? -v[b] : v[b];
+                                }
+                            }
+                            Float a = acc;
+#pragma unroll
+                            for (int b = 0; b < 8; ++b)
+                                a += v[b];
+                            acc = pair_bcast<0xA0>(a);
+                            a = acc;
+#pragma unroll
+                            for (int b = 0; b < 8; ++b)
+                                a += v[b];
+                            acc = pair_bcast<0xF5>(a);
+                        }
+                        if (sub == 0) {
+                            if (is_pi)
+                                spi_s[t] = acc;
+                            else
+                                sp_s[t] = acc;
+                        }
+                    }
+                } else {
                     const int half = lane >> 5; // 1: the overflow chunk
                     const int lane5 = lane & 31;
                     const int u = lane5 & (CW - 1);
