@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -83,6 +84,122 @@ struct DevBuf
         return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel on a
+// device, not of a handle: handles of different shapes live side by side
+// (device_pool, the tests), so every kernel that may ask for more than the
+// 64 KiB default is raised to the LDS of a gfx950 CU once per device instead of
+// to each handle's own plan.
+hipError_t
+set_lds_limits(int device)
+{
+    static std::mutex mu;
+    static std::vector<char> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device >= 0 && static_cast<size_t>(device) < done.size() && done[device])
+        return hipSuccess;
+    const int limit = 160 * 1024;
+    hipError_t e = hipSuccess;
+#define BXH_SET_LDS(...)                                                       \
+    if (e == hipSuccess)                                                       \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, limit)
+    BXH_SET_LDS(bxh::sweep_kernel<float, false>);
+    BXH_SET_LDS(bxh::sweep_kernel<float, true>);
+    BXH_SET_LDS(bxh::sweep_kernel<double, false>);
+    BXH_SET_LDS(bxh::sweep_kernel<double, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_z<float>);
+    BXH_SET_LDS(bxh::sweep_kernel_z<double>);
+    BXH_SET_LDS(bxh::order_post_kernel<float>);
+    BXH_SET_LDS(bxh::order_post_kernel<double>);
+    BXH_SET_LDS(bxh::order_init_kernel<float>);
+    BXH_SET_LDS(bxh::order_init_kernel<double>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 4, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 4, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 5, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 5, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 6, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 6, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 8, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 8, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 4, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 4, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 5, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 5, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 6, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 6, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 8, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 8, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 4, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 4, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 5, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 5, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 6, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 6, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 8, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 8, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 4, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 4, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 5, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 5, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 6, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 6, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 8, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 8, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 4, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 5, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 6, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, false, 8, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 4, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 5, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 6, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<float, true, 8, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 4, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 5, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 6, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, false, 8, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 4, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 5, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 6, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_v2<double, true, 8, false, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_wide<float, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 1, 1>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 1, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 1>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 3>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 4>);
+    BXH_SET_LDS(bxh::sweep_kernel_wide<float, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 1, 1>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 1, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 1>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 3>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 4>);
+    BXH_SET_LDS(bxh::sweep_kernel_wide<double, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 1, 1>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 1, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 1>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 3>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 4>);
+    BXH_SET_LDS(bxh::sweep_kernel_wide<double, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 1, 1>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 1, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 1>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 3>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 4>);
+#undef BXH_SET_LDS
+    if (e != hipSuccess)
+        return e;
+    if (device >= 0) {
+        if (static_cast<size_t>(device) >= done.size())
+            done.resize(static_cast<size_t>(device) + 1, 0);
+        done[device] = 1;
+    }
+    return hipSuccess;
+}
 
 } // namespace
 
@@ -1174,6 +1291,10 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(hipMemset(h->x.p, 0, B * 2 * h->nwords * sizeof(unsigned)));
     HIP_TRY(hipMemset(h->vcount.p, 0, B * sizeof(int)));
     HIP_TRY(hipMemset(h->status.p, 0, B * sizeof(bxh::DevStatus)));
+    // (the state arrays above must be zeros even when BXH_POISON filled the
+    // allocations; those memsets are null-stream work, which the handle's own
+    // non-blocking stream does not wait for)
+    HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_status),
                           B * sizeof(bxh::DevStatus),
                           hipHostMallocDefault));
@@ -1206,10 +1327,12 @@ bxh_create(const bxh_problem* pb,
         const size_t n2big = rmax > bxh::WIDE_SMALL ? static_cast<size_t>(bxh::next_pow2(rmax)) : 0;
         HIP_TRY(h->piw.alloc((B * Gz * (static_cast<size_t>(m) + 1) + 2 * static_cast<size_t>(h->wp.ring) + 64) * h->fsize)); // (+ slack: the window's refill reads whole quarters)
         HIP_TRY(h->whash.alloc(B * hs));
-        HIP_TRY(hipMemset(h->whash.p, 0, B * hs * sizeof(unsigned long long)));
         HIP_TRY(h->wrec.alloc(B * Gz * 8));
         HIP_TRY(h->wcnt.alloc(4 * B + 1));
-        HIP_TRY(hipMemset(h->wcnt.p, 0, (4 * B + 1) * sizeof(unsigned)));
+        // empty hash slots and arrival counters are zeros (also under BXH_POISON):
+        // cleared on the handle's stream, in order with its first launch
+        HIP_TRY(hipMemsetAsync(h->whash.p, 0, B * hs * sizeof(unsigned long long), h->own_stream));
+        HIP_TRY(hipMemsetAsync(h->wcnt.p, 0, (4 * B + 1) * sizeof(unsigned), h->own_stream));
         HIP_TRY(h->vbuf.alloc(B * static_cast<size_t>(rmax)));
         HIP_TRY(h->bkey.alloc(B * (Gz + 2) * n2big));
         HIP_TRY(h->bid.alloc(B * (Gz + 2) * n2big));
@@ -1235,106 +1358,9 @@ bxh_create(const bxh_problem* pb,
         wp.xt = h->xt.p;
         wp.skip_scan = h->xt.p ? 1 : 0;
     wp.own_sort = std::getenv("BXH_WIDE_OWN_SORT") ? 1 : 0;
-        const int wl = static_cast<int>(h->lds_bytes);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, wl));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, wl));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, wl));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, wl));
     }
 
-    if (narrow && h->lds_bytes > 64 * 1024) {
-        const int nl = static_cast<int>(h->lds_bytes);
-#define BXH_SET_NARROW1(F, PM, WW, RQ)                                         \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_narrow<F, PM, WW, RQ>), hipFuncAttributeMaxDynamicSharedMemorySize, nl))
-#define BXH_SET_NARROW(F, PM)                                                  \
-    do {                                                                       \
-        BXH_SET_NARROW1(F, PM, 1, 1);                                          \
-        BXH_SET_NARROW1(F, PM, 1, 2);                                          \
-        BXH_SET_NARROW1(F, PM, 4, 1);                                          \
-        BXH_SET_NARROW1(F, PM, 4, 2);                                          \
-        BXH_SET_NARROW1(F, PM, 4, 3);                                          \
-        BXH_SET_NARROW1(F, PM, 4, 4);                                          \
-    } while (0)
-        BXH_SET_NARROW(float, false);
-        BXH_SET_NARROW(float, true);
-        BXH_SET_NARROW(double, false);
-        BXH_SET_NARROW(double, true);
-#undef BXH_SET_NARROW1
-#undef BXH_SET_NARROW
-    }
-    // the kernels may ask for more than the 64 KiB default dynamic LDS
-    if (!wide_g) {
-        const int want = static_cast<int>(std::max(h->lds_bytes, h->lds_bytes_init));
-#define BXH_SET_LDS(K)                                                         \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&K),             \
-                                hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                want))
-        if (want > 64 * 1024) {
-            BXH_SET_LDS((bxh::sweep_kernel<float, false>));
-            BXH_SET_LDS((bxh::sweep_kernel<float, true>));
-            BXH_SET_LDS((bxh::sweep_kernel<double, false>));
-            BXH_SET_LDS((bxh::sweep_kernel<double, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_z<float>));
-            BXH_SET_LDS((bxh::sweep_kernel_z<double>));
-            BXH_SET_LDS((bxh::order_post_kernel<float>));
-            BXH_SET_LDS((bxh::order_post_kernel<double>));
-            BXH_SET_LDS((bxh::order_init_kernel<float>));
-            BXH_SET_LDS((bxh::order_init_kernel<double>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 5, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 5, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 5, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 5, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 5, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 5, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 5, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 5, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, false>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 4, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 5, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 6, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, false, 8, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 4, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 5, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 6, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<float, true, 8, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 4, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 5, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 6, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, false, 8, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 4, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 5, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 6, false, true>));
-            BXH_SET_LDS((bxh::sweep_kernel_v2<double, true, 8, false, true>));
-        }
-#undef BXH_SET_LDS
-    }
+    HIP_TRY(set_lds_limits(device));
 
     // The forms with several workgroups per instance wait for their partners
     // inside the launch: every workgroup of the grid must be resident at once.
@@ -1735,15 +1761,7 @@ bxh_create_device(const bxh_problem* pb,
     wp.xt = h->xt.p;
     wp.skip_scan = h->xt.p ? 1 : 0;
     wp.own_sort = std::getenv("BXH_WIDE_OWN_SORT") ? 1 : 0;
-    const int wlb = static_cast<int>(h->lds_bytes);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, wlb));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<float, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, wlb));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, wlb));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bxh::sweep_kernel_wide<double, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, wlb));
+    HIP_TRY(set_lds_limits(h->device));
 
     bxh::DevProblem& dp = h->dp;
     dp.m = m;
@@ -2143,13 +2161,17 @@ bxh_reset(bxh_handle h, int inst)
 {
     if (int rc = check_inst(h, inst))
         return rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemset(h->P.p + static_cast<size_t>(inst) * h->nnzp * h->groups * h->fsize,
-                      0,
-                      static_cast<size_t>(h->nnzp) * h->groups * h->fsize));
-    HIP_TRY(hipMemset(h->pi.p + static_cast<size_t>(inst) * h->m * h->fsize,
-                      0,
-                      static_cast<size_t>(h->m) * h->fsize));
+    HIP_TRY(hipSetDevice(h->device));
+    // (stream-ordered like every sweep: a null-stream memset would not be waited
+    // for by the handle's non-blocking stream)
+    HIP_TRY(hipMemsetAsync(h->P.p + static_cast<size_t>(inst) * h->nnzp * h->groups * h->fsize,
+                           0,
+                           static_cast<size_t>(h->nnzp) * h->groups * h->fsize,
+                           h->stream));
+    HIP_TRY(hipMemsetAsync(h->pi.p + static_cast<size_t>(inst) * h->m * h->fsize,
+                           0,
+                           static_cast<size_t>(h->m) * h->fsize,
+                           h->stream));
     return BXH_OK;
 }
 
@@ -2193,7 +2215,8 @@ bxh_order_create(bxh_handle h, int order)
     h->skipped.assign(static_cast<size_t>(h->batch), 0);
     std::fill(h->ostate.begin(), h->ostate.end(), h->use_cycle ? BXH_ORDER_NONE : order);
     const size_t B = static_cast<size_t>(h->batch), LC = static_cast<size_t>(h->lcap);
-    HIP_TRY(hipMemset(h->mlist.p, 0, B * LC * sizeof(int2)));
+    HIP_TRY(hipMemsetAsync(h->mlist.p, 0, B * LC * sizeof(int2), h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     std::vector<int> cnt(B, h->n);
     HIP_TRY(hipMemcpy(h->mcount.p, cnt.data(), B * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->order_b.p, h->ostate.data(), B * sizeof(int), hipMemcpyHostToDevice));
@@ -2638,8 +2661,10 @@ bxh_debug_profile(bxh_handle h, uint64_t* ticks_batch_x32, int reset)
                       h->prof.p,
                       static_cast<size_t>(h->batch) * 32 * sizeof(unsigned long long),
                       hipMemcpyDeviceToHost));
-    if (reset)
-        HIP_TRY(hipMemset(h->prof.p, 0, static_cast<size_t>(h->batch) * 32 * sizeof(unsigned long long)));
+    if (reset) {
+        HIP_TRY(hipMemsetAsync(h->prof.p, 0, static_cast<size_t>(h->batch) * 32 * sizeof(unsigned long long), h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     return BXH_OK;
 }
 

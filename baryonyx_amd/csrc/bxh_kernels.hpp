@@ -4540,9 +4540,12 @@ reinit_kernel(DevProblem pb, DevState st, const ReinitJob* jobs, const unsigned*
                 const bool v = lcg_bernoulli(g, jb.val_p);
                 state = g.s;
                 if (lane == 0) {
+                    // bit_array_impl::set(int, bool) as the reference wrote it
+                    // (bit-array.hpp:144-149): the value only reaches offset 0 of a
+                    // 64-bit block, every other offset is cleared
                     const unsigned bit = 1u << (hit & 31);
                     const unsigned w = xg[hit >> 5];
-                    xg[hit >> 5] = v ? (w | bit) : (w & ~bit);
+                    xg[hit >> 5] = (v && (hit & 63) == 0) ? (w | bit) : (w & ~bit);
                 }
                 from = hit + 1;
             } else

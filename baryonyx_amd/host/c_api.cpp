@@ -254,7 +254,7 @@ bxc_merged(const char* path,
 // blocks of the PREPROCESSED variables), every worker's engine and restart count.
 BX_EXPORT int
 bxc_optimize_trace(const char* path, const bxc_params* p, bxc_result* out, int population, int nwords,
-                   int* pop_remaining, double* pop_value, unsigned long long* pop_hash,
+                   int workers, int* pop_remaining, double* pop_value, unsigned long long* pop_hash,
                    unsigned long long* pop_x, unsigned* worker_rng, long long* worker_calls,
                    long long* rounds, char* err, int errlen)
 {
@@ -285,6 +285,11 @@ bxc_optimize_trace(const char* path, const bxc_params* p, bxc_result* out, int p
             (population > 0 && static_cast<int>(t.pop_x[0].size()) != nwords)) {
             std::snprintf(err, static_cast<size_t>(errlen), "trace shape: population %zu, words %zu",
                           t.pop_value.size(), t.pop_x.empty() ? size_t{ 0 } : t.pop_x[0].size());
+            return -4;
+        }
+        if (static_cast<int>(t.worker_rng.size()) != workers) { // (thread <= 0 means 64 workers)
+            std::snprintf(err, static_cast<size_t>(errlen), "trace shape: %zu workers, room for %d",
+                          t.worker_rng.size(), workers);
             return -4;
         }
         for (int i = 0; i != population; ++i) {

@@ -48,6 +48,14 @@ struct bit_array
     void unset(int i) noexcept { w[i >> 6] &= ~(1ull << (i & 63)); }
     void invert(int i) noexcept { w[i >> 6] ^= 1ull << (i & 63); }
     void set(int i, bool v) noexcept { v ? set(i) : unset(i); }
+    // bit-array.hpp:144-149 as the reference wrote it (`ref ^= (size_t(val) ^ ref) & mask`):
+    // the bit takes `v` at offset 0 of a block and is cleared at every other offset.
+    // Only the mutation loop calls it (itm-optimizer-common.hpp:523).
+    void set_as_reference(int i, bool v) noexcept
+    {
+        const std::uint64_t mask = 1ull << (i & 63);
+        w[i >> 6] ^= (static_cast<std::uint64_t>(v) ^ w[i >> 6]) & mask;
+    }
     int operator[](int i) const noexcept { return static_cast<int>((w[i >> 6] >> (i & 63)) & 1ull); }
     bool operator==(const bit_array& o) const noexcept { return m_size == o.m_size && w == o.w; }
 };
@@ -1252,7 +1260,7 @@ struct recorder
         std::bernoulli_distribution dist_var_p(var_p), dist_value_p(val_p);
         for (int i = 0, e = x.size(); i != e; ++i)
             if (dist_var_p(ctx.rng))
-                x.set(i, dist_value_p(ctx.rng));
+                x.set_as_reference(i, dist_value_p(ctx.rng));
     }
 
     double reinit(local_context& ctx, int worker, const solver_parameters& p, bit_array& x) // :528-554

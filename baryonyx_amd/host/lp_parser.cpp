@@ -550,16 +550,23 @@ read_scp(std::istream& is)
         pb.objective.elements.emplace_back(c, static_cast<int>(j));
     }
     pb.greater_constraints.reserve(static_cast<size_t>(m));
+    // A row is the SET of the columns that cover it: an index listed twice stays
+    // one element with factor 1 (the LP reader would add the factors up to 2 and
+    // send the instance to the Z solver).  seen[j] = last row that listed j.
+    std::vector<long> seen(static_cast<size_t>(n), -1);
     for (long i = 0; i != m; ++i) {
         long k;
-        if (!(is >> k) || k <= 0 || k > n)
+        if (!(is >> k) || k <= 0)
             return raw_problem(tag::bad_constraint);
         std::vector<function_element> elements;
-        elements.reserve(static_cast<size_t>(k));
+        elements.reserve(static_cast<size_t>(std::min(k, n)));
         for (long t = 0; t != k; ++t) {
             long j;
             if (!(is >> j) || j < 1 || j > n)
                 return raw_problem(tag::bad_constraint);
+            if (seen[static_cast<size_t>(j - 1)] == i)
+                continue;
+            seen[static_cast<size_t>(j - 1)] = i;
             elements.emplace_back(1, static_cast<int>(j - 1));
         }
         pb.greater_constraints.emplace_back(pb.strings->append("r" + std::to_string(i + 1)),
@@ -588,6 +595,8 @@ make_problem(const context_ptr& ctx, const std::string& filename)
     if (ends_with(filename, ".scp")) {
         try {
             return read_scp(ifs);
+        } catch (const std::bad_alloc&) {
+            throw; // not a format error: solve / optimize report it as not_enough_memory
         } catch (...) {
             return raw_problem(file_format_error_tag::bad_end_of_file);
         }

@@ -87,7 +87,7 @@ def lib():
                               C.POINTER(C.c_byte), C.c_char_p, C.c_int]
         ullp = C.POINTER(C.c_ulonglong)
         L.bxc_optimize_trace.argtypes = [C.c_char_p, C.POINTER(Params), C.POINTER(Result), C.c_int, C.c_int,
-                                         ip, dp, ullp, ullp, C.POINTER(C.c_uint), C.POINTER(C.c_longlong),
+                                         C.c_int, ip, dp, ullp, ullp, C.POINTER(C.c_uint), C.POINTER(C.c_longlong),
                                          C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
         _LIB = L
     return _LIB
@@ -201,6 +201,8 @@ def optimize_trace(path, params, nvars):
     worker's engine state and restart count, and the rounds run."""
     L = lib()
     pop, thread = params.init_population_size, params.thread
+    if thread <= 0:  # optimize_problem's default pool (itm_gpu.cpp: get_thread_number)
+        thread = 64
     nwords = nvars // 64 + 1
     out = dict(
         pop_remaining=np.zeros(pop, np.int32), pop_value=np.zeros(pop, np.float64),
@@ -212,7 +214,7 @@ def optimize_trace(path, params, nvars):
     err = C.create_string_buffer(256)
     ip, dp, ullp = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)
     rc = L.bxc_optimize_trace(
-        os.fsencode(path), C.byref(params), C.byref(res), pop, nwords,
+        os.fsencode(path), C.byref(params), C.byref(res), pop, nwords, thread,
         out["pop_remaining"].ctypes.data_as(ip), out["pop_value"].ctypes.data_as(dp),
         out["pop_hash"].ctypes.data_as(ullp), out["pop_x"].ctypes.data_as(ullp),
         out["worker_rng"].ctypes.data_as(C.POINTER(C.c_uint)),

@@ -104,6 +104,17 @@ struct BitArray
         else
             unset(i);
     }
+    // bit_array_impl::set(int, bool), bit-array.hpp:144-149, as written there:
+    // `ref ^= (underlying_type(val) ^ ref) & mask` -- `val` widens to 0 / 1, so its
+    // only bit sits at offset 0: the bit at `i` becomes `v` when i % 64 == 0 and is
+    // CLEARED at every other offset whatever `v` is.  The one caller is the mutation
+    // loop (itm-optimizer-common.hpp:523); the x initialisers use set(i) / unset(i).
+    void set_as_reference(int i, bool v) noexcept
+    {
+        const std::uint64_t mask = 1ull << (i & 63);
+        std::uint64_t& ref = w[i >> 6];
+        ref ^= (static_cast<std::uint64_t>(v) ^ ref) & mask;
+    }
     int operator[](int i) const noexcept
     {
         return static_cast<int>((w[i >> 6] >> (i & 63)) & 1ull);

@@ -268,7 +268,7 @@ struct Recorder
         std::bernoulli_distribution dist_value_p(val_p);
         for (int i = 0, e = x.size(); i != e; ++i)
             if (dist_var_p(ctx.rng))
-                x.set(i, dist_value_p(ctx.rng));
+                x.set_as_reference(i, dist_value_p(ctx.rng)); // :523, see BitArray
     }
 
     double reinit(LocalContext& ctx, double kappa_min, double kappa_max, BitArray& x) // :528-554

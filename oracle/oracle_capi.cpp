@@ -658,4 +658,13 @@ orc_exhaustive_solve(int maximize,
     }
 }
 
+void
+orc_bitarray_set_value(uint64_t* words, int index, int val)
+{
+    orc::BitArray a(index + 1);
+    std::copy(words, words + a.block_size(), a.w.begin());
+    a.set_as_reference(index, val != 0);
+    std::copy(a.w.begin(), a.w.end(), words);
+}
+
 } // extern "C"

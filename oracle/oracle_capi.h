@@ -163,6 +163,10 @@ int orc_exhaustive_solve(int maximize,
                          int32_t* ids,
                          int32_t* factors);
 
+/* bit_array_impl::set(int index, bool val) exactly as lib/src/bit-array.hpp:144-149
+ * writes it (the mutation loop's only bit operation, itm-optimizer-common.hpp:523) */
+void orc_bitarray_set_value(uint64_t* words, int index, int val);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,6 +156,8 @@ def lib():
             C.c_int, C.c_int, i32p, C.c_int, C.c_int, f64p, i32p, i32p,
         ]
         L.orc_exhaustive_solve.restype = C.c_int
+        L.orc_bitarray_set_value.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int]
+        L.orc_bitarray_set_value.restype = None
         _LIB = L
     return _LIB
 

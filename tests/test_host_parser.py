@@ -110,3 +110,17 @@ def test_long_rows_parse_in_linear_time(tmp_path):
     dt = time.perf_counter() - t0
     assert info.status == 0 and info.variables == 100000 and info.nnz == inst.nnz
     assert dt < 20.0, dt  # (the quadratic scan: 40 rows x 2e4^2 / 2 + 1e5^2 / 2 compares ~ 1.3e10)
+
+
+def test_scp_row_listing_a_column_twice_keeps_one_element(tmp_path):
+    """A row of an OR-Library file is the set of the columns that cover it: an index
+    listed twice stays one element with factor 1 (summed like an LP row it would be a
+    factor 2 and move the instance to the inequalities-Z solver)."""
+    import numpy as np
+    p = tmp_path / "dup.scp"
+    p.write_text("2 4\n 3 1 4 1\n 3 1 2 1\n 4 4 3 4 2\n")
+    inst = H.merged(str(p), preprocessor=0)
+    assert (inst.m, inst.n, inst.kind) == (2, 4, 1)
+    assert list(inst.row_ptr) == [0, 2, 5]
+    assert list(inst.col) == [0, 1, 3, 2, 1] or sorted(inst.col[:2]) == [0, 1]
+    assert np.all(inst.factor == 1)
