@@ -100,10 +100,17 @@ set_lds_limits(int device)
         return hipSuccess;
     const int limit = 160 * 1024;
     hipError_t e = hipSuccess;
-#define BXH_SET_LDS(...)                                                       \
-    if (e == hipSuccess)                                                       \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, limit)
+    // (a kernel's static LDS counts against the same 160 KiB)
+    auto raise = [&](const void* fn) {
+        if (e != hipSuccess)
+            return;
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, fn);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    limit - static_cast<int>(fa.sharedSizeBytes));
+    };
+#define BXH_SET_LDS(...) raise(reinterpret_cast<const void*>(&__VA_ARGS__))
     BXH_SET_LDS(bxh::sweep_kernel<float, false>);
     BXH_SET_LDS(bxh::sweep_kernel<float, true>);
     BXH_SET_LDS(bxh::sweep_kernel<double, false>);

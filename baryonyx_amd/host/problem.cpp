@@ -203,12 +203,45 @@ make_merged_constraints(const context& ctx, const problem& pb)
         ordered(E, G, L);
         memory();
         break;
-    default: // none, memory; p1..p4 (cost-ratio orders) fall back to none
+    default: // none, memory, p1 .. p4 start from the file order
         ordered(E, L, G);
         std::sort(ret.begin(), ret.end(), [](const auto& l, const auto& r) { return l.id < r.id; });
         if (ctx.parameters.pre_order == po::memory)
             memory();
         break;
+    }
+
+    // make_special_merged_constraints, merged-constraint.cpp:211-284: the rows take
+    // the rank of their cheapest variable by cost / degree (p1: dearest first; p2 - p4
+    // all take the other branch there: cheapest first), the elements of a row go by
+    // falling cost / degree.  The same std::sort calls on the same sequences, so that
+    // ties fall as libstdc++ lets them fall in the reference.
+    if (ctx.parameters.pre_order == po::p1 || ctx.parameters.pre_order == po::p2 ||
+        ctx.parameters.pre_order == po::p3 || ctx.parameters.pre_order == po::p4) {
+        std::vector<int> degree(pb.vars.values.size(), 0);
+        for (const auto& cst : ret)
+            for (const auto& elem : cst.elements)
+                ++degree[elem.variable_index];
+        std::vector<double> variable_cost(pb.vars.values.size(), 0.0);
+        for (const auto& elem : pb.objective.elements)
+            variable_cost[elem.variable_index] = elem.factor / static_cast<double>(degree[elem.variable_index]);
+        std::vector<std::pair<int, double>> ratio_min(ret.size());
+        for (int i = 0, ie = static_cast<int>(ret.size()); i != ie; ++i) {
+            ratio_min[i] = { i, variable_cost[ret[i].elements[0].variable_index] };
+            for (int j = 1, ej = static_cast<int>(ret[i].elements.size()); j != ej; ++j)
+                ratio_min[i].second = std::min(ratio_min[i].second, variable_cost[ret[i].elements[j].variable_index]);
+        }
+        if (ctx.parameters.pre_order == po::p1)
+            std::sort(ratio_min.begin(), ratio_min.end(), [](const auto& l, const auto& r) { return l.second > r.second; });
+        else
+            std::sort(ratio_min.begin(), ratio_min.end(), [](const auto& l, const auto& r) { return l.second < r.second; });
+        for (int i = 0, e = static_cast<int>(ret.size()); i != e; ++i)
+            ret[i].id = ratio_min[i].first;
+        std::sort(ret.begin(), ret.end(), [](const auto& l, const auto& r) { return l.id < r.id; });
+        for (auto& cst : ret)
+            std::sort(cst.elements.begin(), cst.elements.end(), [&variable_cost](const auto& l, const auto& r) {
+                return variable_cost[l.variable_index] > variable_cost[r.variable_index];
+            });
     }
     return ret;
 }

@@ -12,7 +12,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST = os.path.join(_HERE, "host")
 LIB_PATH = os.path.join(HOST, "libbaryonyx_amd.so")
-SOURCES = ["lp_parser.cpp", "problem.cpp", "preprocessor.cpp", "itm_gpu.cpp", "api.cpp", "c_api.cpp"]
+SOURCES = ["lp_parser.cpp", "problem.cpp", "preprocessor.cpp", "itm_gpu.cpp", "api.cpp", "c_api.cpp",
+           "rsurface.cpp"]
 
 
 class Params(C.Structure):
@@ -91,6 +92,63 @@ def lib():
                                          C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
         _LIB = L
     return _LIB
+
+
+class RResult(C.Structure):
+    """bxr_result, include/rbaryonyx.h (the named list of rbaryonyx.cpp:280-288)"""
+    _fields_ = [("solution_found", C.c_int), ("error_found", C.c_int), ("value", C.c_double),
+                ("duration", C.c_double), ("variables", C.c_int), ("constraints", C.c_int),
+                ("remaining_constraints", C.c_int), ("minimize", C.c_int), ("n_solutions", C.c_int),
+                ("solutions", C.POINTER(C.c_double))]
+
+
+# the R exports' arguments with their defaults, in order (rbaryonyx.cpp:368-392, :519-551)
+R_SOLVE_ARGS = [("limit", int, 1000), ("theta", float, 0.5), ("delta", float, -1.0), ("pre_constraint_order", int, 1),
+                ("constraint_order", int, 0), ("kappa_min", float, 0.0), ("kappa_step", float, 1.0e-3),
+                ("kappa_max", float, 0.6), ("alpha", float, 1.0), ("w", float, 0.05), ("time_limit", float, 10.0),
+                ("seed", int, -1), ("thread", int, 1), ("norm", int, 4), ("pushing_k_factor", float, 0.9),
+                ("pushing_objective_amplifier", float, 5.0), ("pushes_limit", int, 100),
+                ("pushing_iteration_limit", int, 50), ("init_policy", int, 0), ("init_policy_random", float, 0.5),
+                ("float_type", int, 1), ("storage_type", int, 1), ("verbose", int, 1)]
+R_OPTIMIZE_ARGS = R_SOLVE_ARGS[:18] + [
+    ("init_crossover_bastert_insertion", float, 0.01), ("init_crossover_solution_selection_mean", float, 0.0),
+    ("init_crossover_solution_selection_stddev", float, 0.3), ("init_mutation_variable_mean", float, 0.0001),
+    ("init_mutation_variable_stddev", float, 0.001), ("init_mutation_value_mean", float, 0.5),
+    ("init_mutation_value_stddev", float, 0.2), ("init_kappa_improve_start", float, 0.0),
+    ("init_kappa_improve_increase", float, 0.02), ("init_kappa_improve_stop", float, 0.2),
+    ("float_type", int, 1), ("storage_type", int, 1), ("verbose", int, 1)]
+
+
+def _r_call(name, spec, file_path, kw):
+    L = lib()
+    fn = getattr(L, name)
+    fn.argtypes = [C.c_char_p] + [C.c_int if t is int else C.c_double for _, t, _ in spec] + [C.POINTER(RResult)]
+    fn.restype = C.c_int
+    unknown = set(kw) - {n for n, _, _ in spec}
+    if unknown:
+        raise TypeError(f"{name}: unknown argument(s) {sorted(unknown)}")
+    args = [t(kw.get(n, d)) for n, t, d in spec]
+    out = RResult()
+    rc = fn(os.fsencode(file_path), *args, C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"{name} -> {rc}")
+    ret = {f: getattr(out, f) for f, _ in RResult._fields_ if f not in ("solutions", "n_solutions")}
+    for f in ("solution_found", "error_found", "minimize"):
+        ret[f] = bool(ret[f])
+    ret["solutions"] = [out.solutions[i] for i in range(out.n_solutions)]
+    L.bxr_free_result.argtypes = [C.POINTER(RResult)]
+    L.bxr_free_result(C.byref(out))
+    return ret
+
+
+def solve_01lp_problem(file_path, **kw):
+    """rbaryonyx's solve_01lp_problem (rbaryonyx.cpp:368-447) -> its nine-field list as a dict."""
+    return _r_call("bxr_solve_01lp_problem", R_SOLVE_ARGS, file_path, kw)
+
+
+def optimize_01lp_problem(file_path, **kw):
+    """rbaryonyx's optimize_01lp_problem (rbaryonyx.cpp:519-618)."""
+    return _r_call("bxr_optimize_01lp_problem", R_OPTIMIZE_ARGS, file_path, kw)
 
 
 def default_params(**kw) -> Params:

@@ -124,3 +124,24 @@ def test_scp_row_listing_a_column_twice_keeps_one_element(tmp_path):
     assert list(inst.row_ptr) == [0, 2, 5]
     assert list(inst.col) == [0, 1, 3, 2, 1] or sorted(inst.col[:2]) == [0, 1]
     assert np.all(inst.factor == 1)
+
+
+def test_cost_ratio_row_orders_p1_p2(tmp_path):
+    """pre_constraint_order p1 .. p4 (merged-constraint.cpp:211-284): variable cost / degree,
+    a row ranks by its cheapest variable (p1: dearest first, p2 - p4: cheapest first), and the
+    elements of every row go by falling cost / degree.  Worked out by hand: degrees a 2, b 2,
+    c 1, d 1 -> cost / degree a 1, b 3, c 8, d 2; row minima r0 {a, b} 1, r1 {b, c} 3,
+    r2 {a, d} 1.  p1 ranks [r1, r0, r2], p2 ranks [r0, r2, r1] (three items: libstdc++ sorts
+    them by insertion, ties keep their order).  The reference then writes the rank list into
+    the rows' ids IN FILE ORDER (`csts[i].id = ratio[i].first`) and sorts the rows by id:
+    p1 -> ids (1, 0, 2) -> rows r1, r0, r2; p2 -> ids (0, 2, 1) -> rows r0, r2, r1."""
+    p = tmp_path / "o.lp"
+    p.write_text("minimize\n 2 a + 6 b + 8 c + 2 d\nst\n r0: a + b >= 1\n r1: b + c >= 1\n r2: a + d >= 1\n"
+                 "binary\n a b c d\nend\n")
+    a, b, c, d = 0, 1, 2, 3
+    r0, r1, r2 = (b, a), (c, b), (d, a)  # elements by falling cost / degree
+    for order, expect in ((8, [r1, r0, r2]), (9, [r0, r2, r1]), (10, [r0, r2, r1]), (11, [r0, r2, r1])):
+        inst = H.merged(str(p), pre_order=order, preprocessor=0)
+        assert inst.m == 3 and inst.n == 4
+        rows = [tuple(int(j) for j in inst.col[inst.row_ptr[k]:inst.row_ptr[k + 1]]) for k in range(3)]
+        assert rows == expect, (order, rows)
