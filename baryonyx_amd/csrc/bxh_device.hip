@@ -259,6 +259,7 @@ struct bxh_handle_s
     DevBuf<unsigned short> col_row16;
     DevBuf<int> sub_ptr, sub_e;      // per-owner row parts (groups > 1)
     DevBuf<int4> sub_desc;
+    DevBuf<int4> chain_rec;          // pipelined sweep: the row chain's descriptor records (DevProblem::chain_rec)
     DevBuf<unsigned char> desc_cost; // cost of each descriptor's column (Float)
     DevBuf<unsigned> ownmask;        // [groups][2*nwords] x bits of each owner
     DevBuf<int> vwork, vpart;        // [batch][groups][m]
@@ -1191,6 +1192,16 @@ bxh_create(const bxh_problem* pb,
         HIP_TRY(h->sub_desc.upload(sd));
     }
     HIP_TRY(h->ownmask.upload(ownmask));
+    if (h->pipe) {
+        // one 16-byte record per CSR element, a row's records in one run: LDS-DMA moves
+        // them into the chain's LDS two rows ahead (64 records per wave and instruction,
+        // hence the padding behind the last row)
+        std::vector<int4> rec(static_cast<size_t>(nnz) + 64, make_int4(0, 16, 0, 0));
+        for (int e = 0; e != nnz; ++e)
+            rec[e] = make_int4(row_cs[e].x, (row_cs[e].y & 0xffff) | ((row_pos[e] - row_cs[e].x) << 16),
+                               pb->col[e], 0);
+        HIP_TRY(h->chain_rec.upload(rec));
+    }
     {
         std::vector<unsigned char> c;
         if (float_type == BXH_FLOAT)
@@ -1419,6 +1430,7 @@ bxh_create(const bxh_problem* pb,
     dp.sub_e = h->sub_e.p;
     dp.sub_desc = h->sub_desc.p;
     dp.desc_cost = h->desc_cost.p;
+    dp.chain_rec = h->chain_rec.p;
     dp.ownmask = h->ownmask.p;
     dp.rmax = rmax;
     dp.cmax = cmax;

@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "bxh_rng.hpp"
 
@@ -55,6 +56,9 @@ struct DevProblem
     const int4* sub_desc;      // per sub_e slot: {first CSC slot, padded length,
                                //  CSC slot of the entry, column}: one load per entry
     const void* desc_cost;     // [nnz] Float: cost of the descriptor's column
+    const int4* chain_rec;     // [nnz + 64] pipelined sweep, row chain: {first CSC slot, padded length |
+                               //  position of the entry in its column << 16, column, 0} of CSR element e:
+                               //  a row's records are one run, moved to LDS two rows ahead by LDS-DMA
     const unsigned* ownmask;   // [groups][2*nwords] x bits of each owner
     const signed char* fac_csr; // [nnz]  coefficient of CSR element (101 kinds)
     // inequalities-Z (general integer coefficients)
@@ -2485,12 +2489,43 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     }
 }
 
+// 16 / 4 bytes per lane from global memory straight into LDS, no registers: lane L's bytes
+// land at lds_dst + 16 * L (4 * L); lds_dst is wave-uniform.  Counted by vmcnt like any load;
+// the data may be read from LDS once the issuing wave has waited for it (and a barrier has
+// passed, for the other waves).
+__device__ inline void
+lds_dma16(const void* src, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n"
+                 "s_mov_b32 m0, %2\n"
+                 "s_nop 0\n"
+                 "global_load_lds_dwordx4 %1, off\n"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+__device__ inline void
+lds_dma4(const void* src, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n"
+                 "s_mov_b32 m0, %2\n"
+                 "s_nop 0\n"
+                 "global_load_lds_dword %1, off\n"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+
 struct LdsPlan2
 {
     int off_pi, off_x, off_val, off_sp, off_cs, off_pe, off_col, off_cost, off_pown, off_spi,
       off_oidx, off_loc, off_stale, off_misc, off_part, off_union, stage_i_off, total;
     // pipelined sweep (role 1: row chain, role 2: producer)
-    int off_mark, off_map, off_flag, off_lnp, off_markl, off_newp, off_patch, off_htab;
+    int off_mark, off_map, off_flag, off_lnp, off_markl, off_newp, off_patch, off_htab, off_land;
 };
 
 template<bool V>
@@ -2553,9 +2588,14 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
     if (role != 2)
         o = al(o + (64 + 8) * 8);
     p.off_mark = p.off_map = p.off_flag = p.off_lnp = p.off_markl = p.off_newp = p.off_patch = o;
+    p.off_land = o;
     if (role == 1) {
-        p.off_markl = o; // entry index of column j in the row that marked it
+        // one 16-bit mark per column: code of the last row position that held it << 10 |
+        // index of the column's entry in that row (the producers keep the code in a byte)
+        p.off_markl = o;
         o = al(o + n * 2);
+        p.off_land = o; // the next row's descriptor records, as LDS-DMA drops them (whole 1 KB pieces)
+        o = al(o + ((rmax + 63) & ~63) * 16);
         p.off_newp = o; // what affect stored for every entry of the row
         o = al(o + rmax * fsize);
         p.off_patch = o; // late entry -> {entry of the previous row in the same column or -1,
@@ -2563,8 +2603,9 @@ lds_plan2(int m, int nwords, int rmax, int romax, int fsize, int slots, int np, 
         o = al(o + 2 * rmax * 4);
     }
     if (role != 0) {
-        p.off_mark = o; // code (1..255, by position mod 255) of the last row that held column j
-        o = al(o + n);
+        p.off_mark = o; // producers: code (1..63, by position mod 63) of the last row that held column j
+        if (role == 2)
+            o = al(o + n);
         p.off_map = o; // chain: the row's late entries; producer: entry or -1
         o = al(o + 2 * rmax * 2);
         p.off_flag = o; // chain: 1 = the entry's column is summed here
@@ -2691,6 +2732,28 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     unsigned short* const markl_s = (unsigned short*)(smem + lp.off_markl);
     Float* const newp_s = (Float*)(smem + lp.off_newp);
     short2* const patch_b = (short2*)(smem + lp.off_patch);
+    // row chain: the landing buffer of the next row's descriptor records, and the cost of the
+    // columns of late entries (low / high words apart: that is how LDS-DMA drops them)
+    const int4* const land_s = (const int4*)(smem + lp.off_land);
+    unsigned* const lc_lo = (unsigned*)(smem + lp.off_cost);
+    unsigned* const lc_hi = lc_lo + 2 * RO;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto chain_cost = [&](int buf, int l) -> Float {
+        if (sizeof(Float) == 8) {
+            const unsigned long long b =
+              (unsigned long long)lc_lo[buf * RO + l] | ((unsigned long long)lc_hi[buf * RO + l] << 32);
+            return (Float)__longlong_as_double((long long)b);
+        }
+        return (Float)__uint_as_float(lc_lo[buf * RO + l]);
+    };
+    auto chain_cost_store = [&](int buf, int l, Float c) {
+        if (sizeof(Float) == 8) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong((double)c);
+            lc_lo[buf * RO + l] = (unsigned)b;
+            lc_hi[buf * RO + l] = (unsigned)(b >> 32);
+        } else
+            lc_lo[buf * RO + l] = __float_as_uint((float)c);
+    };
     unsigned* const cnt_row = st.cnt + inst;
     unsigned* const cnt_end = st.cnt + gridDim.x / NG + inst;
     unsigned* const err_word = st.cnt + 2 * (gridDim.x / NG);
@@ -2726,9 +2789,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         for (int i = tid; i <= pb.rmax; i += T)
             stale_s[i] = staleg[i];
     }
-    if (PIPE)
-        for (int i = tid; i < pb.n; i += T)
-            mark_s[i] = 0;
+    if (PIPE) {
+        if (role == 1)
+            for (int i = tid; i < pb.n; i += T)
+                markl_s[i] = 0;
+        else
+            for (int i = tid; i < pb.n; i += T)
+                mark_s[i] = 0;
+    }
 
     MinStd rng;
     rng.s = st.status[inst].rng; // meaningful in thread 0 only
@@ -2844,7 +2912,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     cs_w[l] = d_cs[s2];
                     pe_w[l] = d_pe[s2];
                     col_w[l] = d_col[s2];
-                    cost_w[l] = d_cost[s2];
+                    if (PIPE && role == 1)
+                        chain_cost_store(buf, l, d_cost[s2]);
+                    else
+                        cost_w[l] = d_cost[s2];
                     if (MW)
                         oidx_w[l] = d_oidx[s2];
                 }
@@ -2855,7 +2926,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 cs_w[l] = pb.row_cs[e];
                 pe_w[l] = pb.row_pos[e];
                 col_w[l] = pb.row_col[e];
-                cost_w[l] = cost[pb.row_col[e]];
+                if (PIPE && role == 1)
+                    chain_cost_store(buf, l, cost[pb.row_col[e]]);
+                else
+                    cost_w[l] = cost[pb.row_col[e]];
                 if (MW)
                     oidx_w[l] = e - x.rs;
             }
@@ -2951,13 +3025,15 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(st.msg + (PIPE ? (size_t)inst * pb.m * 2 : (size_t)0)), 0, PIPE ? pb.m * 16 : 0, 0x00020000);
     const int D = pb.lookahead;
-    // Marks: one byte per column, the code of the last row position that held
-    // it (0: none yet).  A column of the row at position q is late when one
-    // of the D previous positions marked it.  Codes repeat every 255
+    // Marks: per column the code of the last row position that held it (0: none
+    // yet; a byte in the producers, the high six bits of a 16-bit word in the
+    // chain, whose low ten bits are the column's entry in that row).  A column of
+    // the row at position q is late when one
+    // of the D previous positions marked it.  Codes repeat every 63
     // positions: a stale mark can only make an early column late, which both
     // sides decide alike and which is always safe (the chain then sums a
     // column whose rows are all finished).
-    auto code_of = [](int q_) -> int { return q_ % 255 + 1; };
+    auto code_of = [](int q_) -> int { return q_ % 63 + 1; };
     auto is_late = [&](int mk, int q_) -> bool {
         bool late = false;
         for (int d_ = 1; d_ <= D; ++d_)
@@ -3191,6 +3267,143 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         return acc;
     };
 
+    // The row chain's form of sum_m: the late columns' sums are the head of the critical
+    // path of a row (nothing else of the row can start before them), and a column sum is
+    // one chain of c_j dependent additions however the lanes share it.  So (1) what the
+    // prologue needs from LDS comes in two batches (entry + patch record, then extent /
+    // own slot / the previous row's new value) instead of six dependent round trips, (2)
+    // both halves of the wave run ONE instruction stream (the P lanes read their eight
+    // entries of a piece with the same eight 8-byte reads the pi lanes gather with), and
+    // (3) the values of piece i + 1 are read while piece i is added up (two register sets
+    // taking turns; the chain has the registers for it: its load registers are idle while
+    // it sums, a second late chunk of the same wave -- 1.5 % of the rows -- is only asked
+    // for behind the sums).  Same order of additions, same operands.
+    auto sum_late = [&](const int2* cs_r, const int* pe_r, const short* map, int cnt_, int chunk_,
+                        int npm_, int& l_out, Float& dec_out, const short2* patch) -> Float {
+        const int u = (lane & 31) >> 1;
+        const int sub = lane & 1;
+        const bool is_pi = lane >= 32;
+        const int t = chunk_ * CW + u;
+        const int tt = min(t, cnt_ - 1);
+        const int lraw = (int)map[tt];
+        const short2 pp = patch[tt];
+        const int l = t < cnt_ ? lraw : -1;
+        l_out = l;
+        const int lc = max(l, 0);
+        const int2 cs = cs_r[lc];
+        const int pe = pe_r[lc];
+        const Float npv = newp_s[max((int)pp.x, 0)];
+        const int cpad = l >= 0 ? (cs.y & 0xffff) : 0; // (no column: every piece reads zeros)
+        Float* const colp = wst_p + u * SP;
+        const uint2* si2 = reinterpret_cast<const uint2*>(wst_i + u * SI) + 2 * sub;
+        if (l >= 0 && !is_pi && sub == 0) {
+            if (pp.x >= 0) // what the previous row's affect stored for its entry of this column
+                colp[pp.y] = npv;
+            Float* pk = colp + (pe - cs.x);
+            const Float dec = *pk * theta; // P[e] *= theta (stored to HBM by affect)
+            *pk = dec;
+            dec_out = dec;
+        }
+        // (LDS operations of one wave execute in order: the reads below see the patched and
+        // decayed entry; the compiler must not move them up)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // Element offsets from the start of LDS: P lanes walk the staged column, pi lanes
+        // gather pi by the staged row index; a piece past the lane's own column reads
+        // pi_s[m] == +0.0 eight times, and adding +0.0 leaves a sum that began as +0.0 as it
+        // is.  With the piece count of the chunk (wave-uniform) instead of the column's own,
+        // the pieces are straight-line code -- one copy per count: behind a branch that
+        // merges, the compiler's wait counts drain the reads issued ahead.
+        const Float* const fbase = reinterpret_cast<const Float*>(smem);
+        const int p_off = (int)(colp - fbase) + 8 * sub;
+        const int pi_off = (int)(pi_s - fbase);
+        const int z_off = pi_off + pb.m;
+        Float acc = 0;
+        auto run = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            Float v[2][8];
+            unsigned sg[3][4]; // row indices: of the piece being added, the one being read, the next
+            auto read_idx = [&](int k_, unsigned (&o)[4]) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const uint2 w = si2[4 * k_ + b];
+                    o[2 * b] = w.x;
+                    o[2 * b + 1] = w.y;
+                }
+            };
+            auto load_piece = [&](int k_, Float (&o)[8], const unsigned (&ix)[4]) {
+                const bool in = 16 * k_ < cpad;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int idx = (int)((b & 1) ? (ix[b >> 1] >> 16) & 0x7fffu : ix[b >> 1] & 0x7fffu);
+                    const int off = is_pi ? pi_off + idx : p_off + 16 * k_ + b;
+                    o[b] = fbase[in ? off : z_off];
+                }
+            };
+            auto add_piece = [&](Float (&w)[8], const unsigned (&ix)[4]) {
+                if (PM1) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const unsigned neg = (ix[b >> 1] >> ((b & 1) ? 31 : 15)) & 1u;
+                        w[b] = neg ? -w[b] : w[b];
+                    }
+                }
+                Float a = acc; // entries 0-7 (the even lane's), then 8-15 (the odd lane's)
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    a += w[b];
+                acc = pair_bcast<0xA0>(a);
+                a = acc;
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    a += w[b];
+                acc = pair_bcast<0xF5>(a);
+            };
+            read_idx(0, sg[0]);
+            if (K > 1)
+                read_idx(1, sg[1]);
+            load_piece(0, v[0], sg[0]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                // indices two pieces ahead, values one piece ahead, then this piece's additions
+                if (k + 2 < K)
+                    read_idx(k + 2, sg[(k + 2) % 3]);
+                if (k + 1 < K)
+                    load_piece(k + 1, v[(k + 1) & 1], sg[(k + 1) % 3]);
+                add_piece(v[k & 1], sg[k % 3]);
+            }
+        };
+        static_assert(NP <= 8, "one straight-line copy per piece count");
+        switch (npm_) { // wave-uniform
+        case 1:
+            run(std::integral_constant<int, 1>{});
+            break;
+        case 2:
+            run(std::integral_constant<int, 2>{});
+            break;
+        case 3:
+            run(std::integral_constant<int, (NP >= 3 ? 3 : 1)>{});
+            break;
+        case 4:
+            run(std::integral_constant<int, (NP >= 4 ? 4 : 1)>{});
+            break;
+        case 5:
+            run(std::integral_constant<int, (NP >= 5 ? 5 : 1)>{});
+            break;
+        case 6:
+            run(std::integral_constant<int, (NP >= 6 ? 6 : 1)>{});
+            break;
+        case 7:
+            run(std::integral_constant<int, (NP >= 7 ? 7 : 1)>{});
+            break;
+        case 8:
+            run(std::integral_constant<int, (NP >= 8 ? 8 : 1)>{});
+            break;
+        default:
+            break;
+        }
+        return acc;
+    };
+
     if (PIPE && grp > 0) {
         // ---- a producer: the early columns of every row, `D` rows ahead ------
         // Software pipeline over the rows: the loads of a wave's first chunk of
@@ -3215,7 +3428,25 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             if (wave < SW && c * CW < r_)
                 issue_m(cs_b + buf * RO, map_b + buf * pb.rmax, r_, c, chunk_pieces(cs_b + buf * RO, c), DevScope{}, true);
         };
-        v4u mpre = { 0u, 0u, 0u, 0u }; // the message asked for a row ahead (wave 0, lane 0)
+        v4u mpre = { 0u, 0u, 0u, 0u }; // the message asked for a row ahead (every wave for itself)
+        // Position q + 1 reads P once the rows up to position q - D are finished.  Only the
+        // loads of the NEXT row's first chunk ask for that, and each wave issues them at
+        // its own time, behind the staging of its last chunk of this row -- so every wave
+        // checks the chain's message there, for itself (asked for a row ahead: it is there
+        // unless the chain is late), writes the finished row's pi (all waves the same
+        // value; no column still being summed holds that row) and goes on.  Checked by one
+        // thread at the top of the row, with a workgroup barrier behind it, the producers
+        // stood still until the chain's message had come, a third of a row (found with the
+        // timeline build), and the loop chain -> message -> producers -> values -> chain
+        // went round once per row instead of once per D rows.
+        auto await_rows = [&](int need_, int it_) {
+            if (need_ >= 1)
+                pi_s[row_at(need_ - 1)] =
+                  poll_pair(mrsrc, (unsigned)(need_ - 1) * 16u, tag_of(need_), mpre);
+            if (need_ >= 0 && it_ + 2 < nrows)
+                mpre = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, (unsigned)need_ * 16u, 0, 16);
+            asm volatile("" ::: "memory");
+        };
 #ifdef BXH_PROFILE
         unsigned long long pacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, pt = wall_clock64();
 #define BXH_PROD_STAMP(slot)                                                   \
@@ -3254,20 +3485,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 classify_p(x1.re - x1.rs, cur ^ 1, q + 1);
                 BXH_PROD_STAMP(1);
                 BXH_TLP(2);
-                // position q + 1 reads P once the rows up to position q - D are
-                // finished: their pi.  (The columns still being summed for row
-                // it hold none of them.)
-                const int need = q - D;
-                if (tid == 0) {
-                    if (need >= 1)
-                        pi_s[row_at(need - 1)] = poll_pair(mrsrc, (unsigned)(need - 1) * 16u, tag_of(need), mpre);
-                    if (need >= 0 && it + 2 < nrows)
-                        mpre = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, (unsigned)need * 16u, 0, 16);
-                }
             }
+            const int need = q - D; // (see await_rows)
             BXH_PROD_STAMP(2);
             BXH_TLP(3);
-            __syncthreads(); // the next row's map and descriptor; the message has been seen
+            __syncthreads(); // the next row's map and descriptor
             BXH_PROD_STAMP(3);
             BXH_TLP(4);
             const int nchunks = (r + CW - 1) / CW;
@@ -3283,6 +3505,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     // path, for "pending" loads between the loads it issues
                     // next, whose registers it reuses for the addresses.
                     __builtin_amdgcn_s_waitcnt(0x0f70);
+                    await_rows(need, it);
                     first_chunk(x1, cur ^ 1);
                 }
                 int npm = chunk < nchunks ? chunk_pieces(cs_s, chunk) : 0;
@@ -3299,6 +3522,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         npn = chunk_pieces(cs_s, cn);
                         issue_m(cs_s, emap, r, cn, npn, DevScope{}, true);
                     } else if (it + 1 < nrows) {
+                        await_rows(need, it);
                         first_chunk(x1, cur ^ 1);
                     }
                     BXH_PROD_STAMP(7);
@@ -3370,13 +3594,13 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         int* col_w = col_b + buf * RO;
         int2* cs_w = cs_b + buf * RO;
         int* pe_w = pe_b + buf * RO;
-        Float* cost_w = cost_b + buf * RO;
         short* lm = map_b + buf * pb.rmax;
         short2* lpt = patch_b + buf * pb.rmax;
         const int* pe_prev = pe_b + (buf ^ 1) * RO; // the row in front of it: the one being updated
         const int* col_prev = col_b + (buf ^ 1) * RO;
         unsigned char* lf = flag_b + buf * pb.rmax;
         int* ln = lnp_b + buf * LNPW;
+        const bool all_costs = push && PM1; // (a push sweep of the 101 solvers amplifies by the column's cost)
         const int trips = (r_ + stride - 1) / stride;
         for (int s2 = 0; s2 < trips; ++s2) { // (wave-uniform)
             const int l = base + s2 * stride;
@@ -3385,33 +3609,47 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             if (l < r_) {
                 int j;
                 int2 csw;
-                if (rs_ >= 0) {
-                    const int e = rs_ + l;
-                    csw = pb.row_cs[e];
-                    const int pe_ = pb.row_pos[e];
-                    j = pb.row_col[e];
-                    const Float cst = ((const Float*)pb.desc_cost)[e];
+                if (rs_ >= 0) { // the record LDS-DMA left here a row ago
+                    const int4 rec = land_s[l];
+                    csw = make_int2(rec.x, rec.y & 0xffff);
+                    j = rec.z;
                     cs_w[l] = csw;
-                    pe_w[l] = pe_;
+                    pe_w[l] = rec.x + (int)((unsigned)rec.y >> 16);
                     col_w[l] = j;
-                    cost_w[l] = cst;
                 } else {
                     j = col_w[l];
                     csw = cs_w[l];
                 }
-                const int mk = mark_s[j];
+                const unsigned mk16 = markl_s[j];
+                const int mk = (int)(mk16 >> 10);
                 late = is_late(mk, q_);
                 if (q_ >= 2 && mk == code_of(q_ - 1)) { // the previous row holds the column too
-                    ml = markl_s[j];
-                    if (ml >= pr_len || col_prev[ml] != j) // (unless the mark is 255 rows old)
+                    ml = (int)(mk16 & 1023u);
+                    if (ml >= pr_len || col_prev[ml] != j) // (unless the mark is 63 rows old)
                         ml = -1;
                 }
-                mark_s[j] = (unsigned char)code_of(q_);
-                markl_s[j] = (unsigned short)l;
+                markl_s[j] = (unsigned short)((code_of(q_) << 10) | l);
                 lf[l] = late ? 1 : 0;
                 pcs = (csw.y & 0xffff) >> 4;
                 if (ml >= 0)
                     ppos = pe_prev[ml] - csw.x;
+            }
+            if (rs_ >= 0) {
+                // the cost of a late entry's column: asked for here, a row before the late
+                // sums read it, and dropped into lc_lo / lc_hi[buf][l] by LDS-DMA (no
+                // register is held, nothing waits; the wait for the loads in front of
+                // barrier 1 covers it)
+                const bool want = l < r_ && (late || all_costs);
+                if (__ballot(want)) { // wave-uniform
+                    const unsigned dst = lds_base + (unsigned)lp.off_cost +
+                                         (unsigned)(buf * RO + (l - lane)) * 4u; // (l - lane: the wave's first entry)
+                    if (want) {
+                        const char* src = (const char*)pb.desc_cost + (size_t)(rs_ + l) * sizeof(Float);
+                        lds_dma4(src, __builtin_amdgcn_readfirstlane(dst));
+                        if (sizeof(Float) == 8)
+                            lds_dma4(src + 4, __builtin_amdgcn_readfirstlane(dst + (unsigned)(2 * RO) * 4u));
+                    }
+                }
             }
             const unsigned long long bal = __ballot(late);
             if (bal) { // wave-uniform
@@ -3428,11 +3666,23 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             }
         }
     };
+    // the descriptor records of the row at `x`, 1 KB (64 records) per wave and instruction,
+    // by the waves w0, w0 + 1, .. of `nw` (whole pieces: the array is padded)
+    auto dma_records = [&](const RowX& x, int w0, int nw) {
+        const int rr = x.re - x.rs;
+        for (int ch = wave - w0; ch * 64 < rr; ch += nw)
+            lds_dma16(pb.chain_rec + x.rs + ch * 64 + lane,
+                      __builtin_amdgcn_readfirstlane(lds_base + (unsigned)lp.off_land + (unsigned)ch * 1024u));
+    };
     if (PIPE) {
         for (int i = tid; i < 2 * LNPW; i += T)
             lnp_b[i] = 0;
         if (nrows > 0)
             classify_c(x0.re - x0.rs, 0, 1, 0, tid, T, -1);
+        if (nrows > 1) { // row 1 is classified at the top of row 0
+            dma_records(x1, 0, nwaves);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+        }
         __syncthreads();
     }
 
@@ -3522,17 +3772,25 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         ask_values();
                     const int cn = chunk + SW;
                     int npn = 0;
+                    int l;
+                    Float dec = 0;
+#ifdef BXH_CHAIN_SUM_OLD
                     if (cn < nlc) {
                         npn = __builtin_amdgcn_readfirstlane(lnp[cn]);
                         issue_m(cs_s, lmap, nl, cn, npn, CuScope{});
                     }
-                    int l;
-                    Float dec = 0;
                     const Float acc = sum_m(cs_s, pe_s, lmap, nl, chunk, l, dec, lpatch);
+#else
+                    const Float acc = sum_late(cs_s, pe_s, lmap, nl, chunk, npm, l, dec, lpatch);
+                    if (cn < nlc) {
+                        npn = __builtin_amdgcn_readfirstlane(lnp[cn]);
+                        issue_m(cs_s, lmap, nl, cn, npn, CuScope{});
+                    }
+#endif
                     BXH_TL(15);
                     const Float spi = __shfl_down(acc, 32); // the pi lanes of the same column
                     if (l >= 0 && lane < 32 && (lane & 1) == 0) {
-                        const Float cj = cost_s[l]; // (linear objective: the host checks)
+                        const Float cj = chain_cost(cur, l); // (linear objective: the host checks)
                         Float v = cj - spi - acc;
                         if (PM1 && pb.fac_csr[rs + l] < 0)
                             v = -v;
@@ -3813,7 +4071,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         Float v = poll_pair(xrsrc, roff + (unsigned)l * 16u, tagq, gG[s2]);
                         pown_s[l] = gP[s2] * theta;
                         if (push) // the 01 solvers index the cost with the LOCAL id (quirk)
-                            v += obj_amp * (PM1 ? cost_s[l] : cost[l]);
+                            v += obj_amp * (PM1 ? chain_cost(cur, l) : cost[l]);
                         val_s[l] = v;
                     }
                 }
@@ -3932,6 +4190,11 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 __builtin_amdgcn_raw_buffer_store_b128(pair_of(pi_s[kprev], tag_of(it)), mrsrc,
                                                        (unsigned)(it - 1) * 16u, 0, 16);
             kprev = k;
+            // the records of the row after the next: the landing buffer is free (the next
+            // row was classified in front of this barrier), they are read at the top of
+            // the next row
+            if (wave >= SW && it + 2 < nrows)
+                dma_records(x2, SW, nwaves - SW);
             prefetch_rows();
         }
         if (it + 1 < nrows)
@@ -3963,9 +4226,30 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             unsigned long long A = ~0ull, A2 = ~0ull, B = ~0ull, C = ~0ull, D = ~0ull;
             int cN = 0, cZ = 0;
             bool flagged[2] = { false, false };
+            // Row chain: behind barrier 1 the staging waves issue the next row's late
+            // loads (twenty load instructions each), so the keys of the row go to the
+            // other waves first -- two entries per thread there, the staging waves take
+            // what is left (nothing at the scpnrh shape) and then skip the reductions.
+            int ke[2] = { tid, tid + T };
+#ifndef BXH_KEYS_EVEN
+            if (PIPE) {
+                const int STG = SW * 64, OTH = T - STG;
+                if (wave >= SW) {
+                    ke[0] = tid - STG;
+                    ke[1] = OTH + tid - STG;
+                } else {
+                    ke[0] = 2 * OTH + tid;
+                    ke[1] = 2 * OTH + STG + tid;
+                }
+            }
+            const bool kskip = PIPE && (ke[0] & ~63) >= r; // wave-uniform: no entry of the row here
+#else
+            const bool kskip = false;
+#endif
+            if (!kskip) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int e = tid + s2 * T;
+                const int e = ke[s2];
                 const bool have = e < r;
                 unsigned long long k = ~0ull;
                 if (have) {
@@ -4033,6 +4317,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     if (wtie)
                         atomicOr(&part_s[68], 1ull);
                 }
+            }
+            } else if ((tid & 63) == 0) { // no keys in this wave: neutral partial minima
+                part_s[(tid >> 6) * 2] = ~0ull;
+                part_s[(tid >> 6) * 2 + 1] = ~0ull;
             }
             BXH_STAMP(8);
             BXH_TL(8);
@@ -4167,6 +4455,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             BXH_STAMP(10);
             BXH_TL(10);
         }
+        if (PIPE && wave >= SW) // the records asked for behind barrier 1 are in LDS (long since;
+            __builtin_amdgcn_s_waitcnt(0x0f70); // in front of the stores below, which would be waited for too)
         if (fast) {
             BXH_STAMP(1);
             // ---- affect without the sorted order ------------------------------
@@ -4187,8 +4477,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 const int l = tid + s2 * T; // own entries only
                 if (l < ro) {
                     const int idx = MW ? oidx_s[l] : l;
+                    // (row chain: the keys were formed by other threads, see above)
                     const unsigned long long key =
-                      MW ? order_key<Float>(val_s[idx], maximize) : mykey[s2];
+                      (MW || PIPE) ? order_key<Float>(val_s[idx], maximize) : mykey[s2];
                     const int j = col_s[l];
                     const int pe = pe_s[l];
                     bool up = mode == 1 || (mode == 2 && key <= thr);
