@@ -4272,8 +4272,18 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 C = umin64(C, isN ? ~k : ~0ull);
                 D = umin64(D, isS ? k : ~0ull);
             }
+            // wave reductions (uniform results); the second smallest is the
+            // minimum of what is left once the wave's smallest key is known
+            // (keys are distinct unless the row has a tie, which takes the
+            // sort path anyway)
+            const unsigned long long ownA = A;
+            wave_umin64x4(A, B, C, D);
+            unsigned long long E = ownA == A ? A2 : ownA;
+            E = wave_umin64(E);
             // a flagged key is looked up in the whole row by its wave (rare:
-            // the bitmap is 128 times larger than the row)
+            // the bitmap is 128 times larger than the row).  Behind the reductions:
+            // what the filter's atomics returned is first read here, so their round
+            // trip runs under the DPP chains above.
             bool wtie = false;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -4296,14 +4306,6 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         wtie = true;
                 }
             }
-            // wave reductions (uniform results); the second smallest is the
-            // minimum of what is left once the wave's smallest key is known
-            // (keys are distinct unless the row has a tie, which takes the
-            // sort path anyway)
-            const unsigned long long ownA = A;
-            wave_umin64x4(A, B, C, D);
-            unsigned long long E = ownA == A ? A2 : ownA;
-            E = wave_umin64(E);
             {
                 const int wave = tid >> 6, lane = tid & 63;
                 if (lane == 0) {
@@ -4333,6 +4335,15 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             // after a sort-path row).
             {
                 const int nw = T >> 6;
+                // everything the selection may read from LDS, asked for in one batch behind the
+                // barrier (one round trip instead of one per use: this stretch runs on every wave
+                // of the workgroup at once and is nothing but latency)
+                const int lane_u = tid & 63;
+                const int pre_bmin = misc_s[MS_BMIN], pre_bmax = misc_s[MS_BMAX], pre_bneg = misc_s[MS_BNEG];
+                const Float pre_pi = pi_s[k];
+                const Float pre_stale = stale_s[r];
+                const unsigned long long pre_a1 = part_s[(lane_u < nw ? lane_u : 0) * 2],
+                                         pre_a2 = part_s[(lane_u < nw ? lane_u : 0) * 2 + 1];
                 const unsigned long long g1 = uniform_u64(part_s[69]);
                 const unsigned long long gx = uniform_u64(part_s[64]), gxN = uniform_u64(part_s[65]),
                                          gnS = uniform_u64(part_s[66]);
@@ -4340,12 +4351,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 // over the waves of "second smallest of the wave that holds
                 // g1, smallest of the others"
                 auto second_smallest = [&]() -> unsigned long long {
-                    const int lane = tid & 63;
                     unsigned long long cnd = ~0ull;
-                    if (lane < nw) {
-                        const unsigned long long a1 = part_s[lane * 2], a2 = part_s[lane * 2 + 1];
-                        cnd = a1 == g1 ? a2 : a1;
-                    }
+                    if (lane_u < nw)
+                        cnd = pre_a1 == g1 ? pre_a2 : pre_a1;
                     return wave_umin64(cnd);
                 };
                 const unsigned long long cnt = uniform_u64(part_s[67]);
@@ -4363,8 +4371,8 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                             return rng.coin();
                         return maximize ? v < 0 : v > 0;
                     };
-                    const int c_size = PM1 ? misc_s[MS_BNEG] : 0;
-                    int bkmin = misc_s[MS_BMIN], bkmax = misc_s[MS_BMAX];
+                    const int c_size = PM1 ? pre_bneg : 0;
+                    int bkmin = pre_bmin, bkmax = pre_bmax;
                     if (kind == 0 || kind == 2 || bkmin == bkmax) {
                         sel = min(bkmin + c_size, r) - 1;
                     } else {
@@ -4391,7 +4399,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                                 if (cur < r)
                                     stopped = true; // first S entry
                                 else
-                                    stopped = stop(stale_s[r]); // R[r_size] (stale)
+                                    stopped = stop(pre_stale); // R[r_size] (stale)
                             }
                             if (stopped)
                                 sel = cur - 1;
@@ -4438,7 +4446,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                         f_mode = 1;
                     } else {
                         const Float v_sel1 = key_value<Float>(k_sel1, maximize);
-                        const Float old_pi = pi_s[k];
+                        const Float old_pi = pre_pi;
                         const Float new_pi = old_pi + ((v_sel + v_sel1) / two);
                         d += kfac * (v_sel1 - v_sel);
                         f_mode = 2;
