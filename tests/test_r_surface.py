@@ -53,10 +53,12 @@ def test_solve_and_optimize_through_the_r_surface(tmp_path):
     r = H.solve_01lp_problem(lp, seed=7, limit=500, verbose=0)
     assert list(r) == FIELDS
     assert r["solution_found"] and not r["error_found"] and r["minimize"]
-    assert r["variables"] > 0 and r["constraints"] > 0 and r["remaining_constraints"] == 0
+    # (solve_problem leaves result.remaining_constraints at its default, INT_MAX, core:732-736 /
+    # itm-solver-common.hpp:216-224 -- only optimize_problem fills it -- and the glue passes it on)
+    assert r["variables"] > 0 and r["constraints"] > 0 and r["remaining_constraints"] == 2**31 - 1
     assert r["solutions"] and r["value"] == r["solutions"][-1] > 0
     # the same call through baryonyx::solve with the parameters the glue sets (pre_order = memory)
-    p = H.default_params(seed=7, limit=500, pre_order=1, time_limit=10.0, thread=1, storage=1)
+    p = H.default_params(seed=7, limit=500, pre_order=1, time_limit=10.0, thread=1)
     ref, _ = H.run(lp, 0, p)
     assert ref.status == 0 and ref.value == r["value"]
     o = H.optimize_01lp_problem(lp, seed=7, thread=8, time_limit=2.0, verbose=0)
