@@ -109,6 +109,21 @@ def test_scpnrh_shaped_rows(oracle, bxh, groups, monkeypatch):
     run_case(oracle, bxh, inst, 0, False, 0, 0.0, batch=2, sweeps=4, push_at=(3,))
 
 
+@pytest.mark.parametrize("groups", ["4", "p4"])
+@pytest.mark.parametrize("float_type", [1, 0])
+def test_long_pm1_rows_with_push_sweeps(oracle, bxh, groups, float_type, monkeypatch):
+    """Rows of ~600 elements with -1 coefficients (inequalities-101), push sweeps among
+    them: in the pipelined form that is the third pass of the chain's row classification
+    (entries past 512), the second prefetched value of a thread, and -- push sweeps of the
+    101 solvers amplify by the COLUMN's cost -- the cost of every entry, not only of the late
+    ones, moved into LDS by LDS-DMA.  Rows 64 apart meet the same mark code again."""
+    monkeypatch.setenv("BXH_GROUPS", groups)
+    inst = synth.make_pm1(140, 2000, 0.3, "int", 61)
+    assert int(np.diff(inst.row_ptr).max()) > 560
+    run_case(oracle, bxh, inst, float_type, False, 0, 0.1, batch=2, sweeps=5, push_at=(1, 3),
+             expect_form=44 if groups == "p4" else None)
+
+
 ORDER_CASES = [
     # (name, maker, float_type, maximize, order, x0_density, push_at)
     ("infeas-decr-pm1", lambda: synth.make_pm1(50, 250, 0.06, "int", 41), 1, False, 3, 0.3, (5, 9)),
