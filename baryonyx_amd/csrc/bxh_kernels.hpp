@@ -523,6 +523,25 @@ filter_insert(unsigned* bitmap, unsigned long long key)
     return (atomicOr(&bitmap[word], bits) & bits) == bits;
 }
 
+// The same in two halves: the atomic is issued here, what it returned is looked at by
+// filter_hit() -- later, so that its round trip runs under other work.
+__device__ inline unsigned
+filter_issue(unsigned* bitmap, unsigned long long key, unsigned& bits)
+{
+    unsigned x = (unsigned)(key >> 32) * 0x9E3779B1u + (unsigned)key * 0x85EBCA77u;
+    x ^= x >> 15;
+    x *= 0xC2B2AE3Du;
+    x ^= x >> 13;
+    const unsigned word = x >> 21;
+    bits = (1u << (x & 31)) | (1u << ((x >> 5) & 31)) | (1u << ((x >> 10) & 31));
+    return atomicOr(&bitmap[word], bits);
+}
+__device__ inline bool
+filter_hit(unsigned old, unsigned bits)
+{
+    return (old & bits) == bits;
+}
+
 // Open-addressing insert of a non-zero key; returns true when the key was
 // already there (two equal reduced costs in the row).
 __device__ inline bool
@@ -4226,6 +4245,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             unsigned long long A = ~0ull, A2 = ~0ull, B = ~0ull, C = ~0ull, D = ~0ull;
             int cN = 0, cZ = 0;
             bool flagged[2] = { false, false };
+            unsigned f_old[2] = { 0u, 0u }, f_bits[2] = { 1u, 1u }; // (the filter's answers, read behind the reductions)
             // Row chain: behind barrier 1 the staging waves issue the next row's late
             // loads (twenty load instructions each), so the keys of the row go to the
             // other waves first -- two entries per thread there, the staging waves take
@@ -4254,7 +4274,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 unsigned long long k = ~0ull;
                 if (have) {
                     k = order_key<Float>(val_s[e], maximize);
-                    flagged[s2] = filter_insert(reinterpret_cast<unsigned*>(htab), k);
+                    f_old[s2] = filter_issue(reinterpret_cast<unsigned*>(htab), k, f_bits[s2]);
                 }
                 mykey[s2] = have ? k : 0ull;
                 const bool isN = have && k < K0, isZ = have && k == K0;
@@ -4285,8 +4305,10 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             // what the filter's atomics returned is first read here, so their round
             // trip runs under the DPP chains above.
             bool wtie = false;
+            asm volatile("" : "+v"(f_old[0]), "+v"(f_old[1])); // (not before the reductions above)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                flagged[s2] = filter_hit(f_old[s2], f_bits[s2]);
                 unsigned long long pending = __ballot(flagged[s2]);
                 while (pending && !wtie) { // one confirmed tie settles the row
                     const int src = __ffsll((long long)pending) - 1;
