@@ -2887,6 +2887,31 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         x2 = row_extent(row_at(2));
     RowX x3 = x2;
     int k3 = nrows > 3 ? row_at(3) : 0, k4 = 0;
+    // The extents of the row three ahead and the id of the row four ahead are asked for in
+    // the middle of a row, for the rows' shift at its end.  Their addresses are uniform; as
+    // vector loads the compiler moved each value to a scalar register right behind its load --
+    // a `s_waitcnt vmcnt(0)` per load in the middle of the row: two global round trips one
+    // behind the other on every wave, and on the chain's staging waves a wait for the late
+    // loads they had just issued (2 400 of a row's 18 000 cycles, found with the LDS-stamped
+    // timeline).  row_ptr / sub_ptr never change, and neither does the row list while the
+    // rows are walked in its own order (orders none / reversing: the private copy is the
+    // list): read through the constant address space they are scalar loads, which no vector
+    // memory counter waits for.
+    typedef const __attribute__((address_space(4))) int* cint_p;
+    const cint_p row_ptr_c = (cint_p)pb.row_ptr;
+    const cint_p sub_ptr_c = (cint_p)sub_ptr;
+    const cint_p vlist_c = (cint_p)vlist;
+    auto prefetch_x3k4 = [&](int it_) {
+        if (it_ + 3 < nrows) {
+            x3.k = k3;
+            x3.rs = row_ptr_c[k3];
+            x3.re = row_ptr_c[k3 + 1];
+            x3.os = MW ? sub_ptr_c[k3] : 0;
+            x3.oe = MW ? sub_ptr_c[k3 + 1] : 0;
+            if (it_ + 4 < nrows)
+                k4 = ord == 0 ? vlist_c[it_ + 4] : (ord == 1 ? vlist_c[nrows - 1 - (it_ + 4)] : row_at(it_ + 4));
+        }
+    };
     // descriptor of a row's own entries (column start / padded length | chunk
     // pieces, CSC slot, column, cost, position in the whole row) in registers
     int2 d_cs[2];
@@ -3571,11 +3596,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             BXH_TLP(13);
             if (it + 2 < nrows) {
                 fetch_desc(x2);
-                if (it + 3 < nrows) {
-                    x3 = row_extent(k3);
-                    if (it + 4 < nrows)
-                        k4 = row_at(it + 4);
-                }
+                prefetch_x3k4(it);
             }
             BXH_PROD_STAMP(5);
             BXH_TLP(14);
@@ -4119,24 +4140,15 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         // (loads only: nothing here waits; the chain issues them behind
         // barrier 1, after the loads of the next row's late columns)
         auto prefetch_rows = [&]() { // (the chain's descriptors do not travel through registers)
-            if (it + 2 < nrows) {
-                if (it + 3 < nrows) {
-                    x3 = row_extent(k3);
-                    if (it + 4 < nrows)
-                        k4 = row_at(it + 4);
-                }
-            }
+            if (it + 2 < nrows)
+                prefetch_x3k4(it);
             if (it + 1 < nrows)
                 fetch_consts(x1.k);
         };
         if (PIPE) {
         } else if (it + 2 < nrows) {
             fetch_desc(x2);
-            if (it + 3 < nrows) {
-                x3 = row_extent(k3);
-                if (it + 4 < nrows)
-                    k4 = row_at(it + 4);
-            }
+            prefetch_x3k4(it);
         }
         if (!PIPE && it + 1 < nrows)
             fetch_consts(x1.k);
