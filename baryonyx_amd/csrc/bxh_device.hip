@@ -1137,7 +1137,6 @@ bxh_create(const bxh_problem* pb,
     HIP_TRY(h->row_ptr.upload(std::vector<int>(pb->row_ptr, pb->row_ptr + m + 1)));
     HIP_TRY(h->row_col.upload(std::vector<int>(pb->col, pb->col + nnz)));
     HIP_TRY(h->row_pos.upload(row_pos));
-    HIP_TRY(h->row_cs.upload(row_cs));
     HIP_TRY(h->col_start.upload(col_start));
     HIP_TRY(h->col_len.upload(col_len));
     HIP_TRY(h->col_row.upload(col_row));
@@ -1196,12 +1195,43 @@ bxh_create(const bxh_problem* pb,
         // one 16-byte record per CSR element, a row's records in one run: LDS-DMA moves
         // them into the chain's LDS two rows ahead (64 records per wave and instruction,
         // hence the padding behind the last row)
+        // The neighbours of every entry in its column: how many rows up / down the column's
+        // previous / next entry sits (clipped to 15, 0 = none) and, where that is the very
+        // next row, the entry's index in it.  When a sweep walks consecutive rows (every full
+        // sweep in the orders none / reversing), "which of the D rows before this one hold the
+        // column" is this static gap, and neither the chain nor the producers need their
+        // column marks (bxh_kernels.hpp: smode).  w = up | down << 4 | index up << 8 | index
+        // down << 18; the producers find the two gaps in bits 24 .. 31 of row_cs[e].y.
+        std::vector<unsigned> nb(static_cast<size_t>(nnz), 0u);
+        {
+            std::vector<int> last(static_cast<size_t>(n), -1); // last element seen in column j
+            for (int k = 0; k != m; ++k)
+                for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e) {
+                    const int j = pb->col[e];
+                    const int pe_ = last[j];
+                    if (pe_ >= 0) {
+                        // the row of element pe_: its CSC slot is the one in front of e's
+                        const int kp = col_row[static_cast<size_t>(row_pos[e]) - 1] & 0x3fffffff;
+                        const unsigned gap = static_cast<unsigned>(std::min(k - kp, 15));
+                        nb[e] |= gap;
+                        nb[pe_] |= gap << 4;
+                        if (gap == 1) {
+                            nb[e] |= static_cast<unsigned>(pe_ - pb->row_ptr[kp]) << 8;
+                            nb[pe_] |= static_cast<unsigned>(e - pb->row_ptr[k]) << 18;
+                        }
+                    }
+                    last[j] = e;
+                }
+        }
         std::vector<int4> rec(static_cast<size_t>(nnz) + 64, make_int4(0, 16, 0, 0));
-        for (int e = 0; e != nnz; ++e)
+        for (int e = 0; e != nnz; ++e) {
             rec[e] = make_int4(row_cs[e].x, (row_cs[e].y & 0xffff) | ((row_pos[e] - row_cs[e].x) << 16),
-                               pb->col[e], 0);
+                               pb->col[e], static_cast<int>(nb[e]));
+            row_cs[e].y = (row_cs[e].y & 0x00ffffff) | static_cast<int>((nb[e] & 0xffu) << 24);
+        }
         HIP_TRY(h->chain_rec.upload(rec));
     }
+    HIP_TRY(h->row_cs.upload(row_cs)); // (behind the block above: it adds the gaps)
     {
         std::vector<unsigned char> c;
         if (float_type == BXH_FLOAT)

@@ -183,6 +183,37 @@ struct Prof
 // the row chain of instance 0 writes the shader clock at 16 points of rows 200..207 into
 // the profile buffer ([row][wave][point]).  Not for any other use.
 #ifdef BXH_TIMELINE
+#ifdef BXH_TIMELINE_LDS
+// Stamps without stores in between (-DBXH_TIMELINE_LDS, tools/debug/chain_timeline_light.py):
+// six points per wave (-DBXH_TL_P0 .. P5; default 3, 6, 7, 8, 9, 12) go to LDS (part_s[16 ..])
+// and are written out at the top of the next row.  A global store in front of a
+// `s_waitcnt vmcnt(0)` (there is one on either side of barrier 1) costs its round trip, and
+// the full-stamp build shows that round trip as time of the phase behind the stamp.
+#ifndef BXH_TL_P0
+#define BXH_TL_P0 3
+#define BXH_TL_P1 6
+#define BXH_TL_P2 7
+#define BXH_TL_P3 8
+#define BXH_TL_P4 9
+#define BXH_TL_P5 12
+#endif
+#define BXH_TL_SLOT(p_) ((p_) == BXH_TL_P0 ? 0 : (p_) == BXH_TL_P1 ? 1 : (p_) == BXH_TL_P2 ? 2 : (p_) == BXH_TL_P3 ? 3 : (p_) == BXH_TL_P4 ? 4 : (p_) == BXH_TL_P5 ? 5 : -1)
+#define BXH_TL(p_)                                                             \
+    do {                                                                       \
+        if (PIPE && grp == 0 && inst == 0 && (tid & 63) == 0) {                \
+            if ((p_) == 0 && it >= 201 && it < 209) {                          \
+                const int pts_[6] = { BXH_TL_P0, BXH_TL_P1, BXH_TL_P2, BXH_TL_P3, BXH_TL_P4, BXH_TL_P5 }; \
+                for (int s_ = 0; s_ < 6; ++s_)                                 \
+                    st.prof[((it - 201) * 8 + (tid >> 6)) * 16 + pts_[s_]] = part_s[16 + (tid >> 6) * 6 + s_]; \
+            }                                                                  \
+            if (BXH_TL_SLOT(p_) >= 0 && it >= 200 && it < 208)                 \
+                part_s[16 + (tid >> 6) * 6 + BXH_TL_SLOT(p_)] = (unsigned long long)clock64(); \
+        }                                                                      \
+    } while (0)
+#define BXH_TLP(p_)                                                            \
+    do {                                                                       \
+    } while (0)
+#else
 #define BXH_TL(p_)                                                             \
     do {                                                                       \
         if (PIPE && grp == 0 && inst == 0 && it >= 200 && it < 208 && (tid & 63) == 0) \
@@ -194,6 +225,7 @@ struct Prof
         if (PIPE && grp == 1 && inst == 0 && it >= 200 && it < 208 && (tid & 63) == 0) \
             st.prof[1024 + ((it - 200) * 8 + (tid >> 6)) * 16 + (p_)] = (unsigned long long)clock64(); \
     } while (0)
+#endif
 #else
 #define BXH_TL(p_)                                                             \
     do {                                                                       \
@@ -2841,6 +2873,20 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     // (pi_sign_change keeps the shuffled R: written back behind the row loop,
     // when every partner has copied the list)
     rng.s = (unsigned)misc_s[MS_RNG];
+    // Pipelined sweep over CONSECUTIVE rows (every full sweep in the orders none /
+    // reversing): the rows before a row are k - 1, k - 2, .. (k + 1, .. when reversing), so
+    // "which of the D previous rows hold this column" is the static gap to the column's
+    // neighbouring entry that bxh_create put into the descriptors -- no column marks, no
+    // look-up of the previous row's entry.  smode 1: ascending, 2: descending, 0: any other
+    // list (the marks).  Chain and producers decide alike: they walk the same list.
+    int smode = 0;
+    if (PIPE && (ord == 0 || ord == 1)) {
+        int bad = 0;
+        for (int i = tid; i + 1 < nrows; i += T)
+            bad |= (vrows[i + 1] - vrows[i] != 1);
+        if (!__syncthreads_or(bad))
+            smode = ord == 0 ? 1 : 2;
+    }
 
     const int l8 = tid & 7;
     // The duties of a single thread (row constants, pi_k and d of a row, the
@@ -3035,7 +3081,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     const char* const Pb = reinterpret_cast<const char*>(P);
     const char* const Ib = reinterpret_cast<const char*>(crow);
     auto chunk_pieces = [&](const int2* cs_r, int chunk) -> int {
-        return __builtin_amdgcn_readfirstlane(cs_r[chunk * CW].y >> 16);
+        return __builtin_amdgcn_readfirstlane((cs_r[chunk * CW].y >> 16) & 0xff);
     };
     auto issue = [&](const int2* cs_r, int ro_, int chunk, int npm) {
 #pragma unroll
@@ -3459,6 +3505,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
         auto classify_p = [&](int r_, int buf, int q_) {
             const int* col_w = col_b + buf * RO;
             short* em = map_b + buf * pb.rmax;
+            if (smode) { // consecutive rows: late = the column's neighbour is at most D rows away
+                const int2* cs_w = cs_b + buf * RO;
+                for (int l = tid; l < r_; l += T) {
+                    const int g = (cs_w[l].y >> (smode == 1 ? 24 : 28)) & 15;
+                    em[l] = (g >= 1 && g <= D) ? (short)-1 : (short)l;
+                }
+                return;
+            }
             for (int l = tid; l < r_; l += T) {
                 const int j = col_w[l];
                 const int mk = mark_s[j];
@@ -3647,19 +3701,38 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             bool late = false;
             int pcs = 0, ml = -1, ppos = 0;
             if (l < r_) {
-                int j;
+                int j, recw = 0, ownpos;
                 int2 csw;
                 if (rs_ >= 0) { // the record LDS-DMA left here a row ago
                     const int4 rec = land_s[l];
                     csw = make_int2(rec.x, rec.y & 0xffff);
                     j = rec.z;
+                    recw = rec.w;
+                    ownpos = (int)((unsigned)rec.y >> 16);
                     cs_w[l] = csw;
-                    pe_w[l] = rec.x + (int)((unsigned)rec.y >> 16);
+                    pe_w[l] = rec.x + ownpos;
                     col_w[l] = j;
                 } else {
                     j = col_w[l];
                     csw = cs_w[l];
+                    ownpos = pe_w[l] - csw.x;
+                    recw = (csw.y >> 24) & 0xff; // (the two gaps; the first row of a walk has no row in front of it)
+                    csw.y &= 0xffff;
                 }
+                if (smode) {
+                    // consecutive rows: the gap to the column's neighbouring entry says it all
+                    // (the neighbour in the very next row is this column's entry of the
+                    // previous row of the walk, one slot up / down the column)
+                    const unsigned w = (unsigned)recw;
+                    const int g = (int)(smode == 1 ? w & 15u : (w >> 4) & 15u);
+                    late = g >= 1 && g <= D;
+                    if (g == 1 && q_ >= 2) {
+                        ml = (int)((smode == 1 ? w >> 8 : w >> 18) & 1023u);
+                        ppos = ownpos + (smode == 1 ? -1 : 1);
+                    }
+                    lf[l] = late ? 1 : 0;
+                    pcs = (csw.y & 0xffff) >> 4;
+                } else {
                 const unsigned mk16 = markl_s[j];
                 const int mk = (int)(mk16 >> 10);
                 late = is_late(mk, q_);
@@ -3673,6 +3746,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                 pcs = (csw.y & 0xffff) >> 4;
                 if (ml >= 0)
                     ppos = pe_prev[ml] - csw.x;
+                }
             }
             if (rs_ >= 0) {
                 // the cost of a late entry's column: asked for here, a row before the late
@@ -4308,6 +4382,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             // minimum of what is left once the wave's smallest key is known
             // (keys are distinct unless the row has a tie, which takes the
             // sort path anyway)
+#ifdef BXH_TL_KEYS
+            if (wave >= SW) BXH_TL(13);
+#endif
             const unsigned long long ownA = A;
             wave_umin64x4(A, B, C, D);
             unsigned long long E = ownA == A ? A2 : ownA;
@@ -4316,6 +4393,9 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             // the bitmap is 128 times larger than the row).  Behind the reductions:
             // what the filter's atomics returned is first read here, so their round
             // trip runs under the DPP chains above.
+#ifdef BXH_TL_KEYS
+            if (wave >= SW) BXH_TL(15);
+#endif
             bool wtie = false;
             asm volatile("" : "+v"(f_old[0]), "+v"(f_old[1])); // (not before the reductions above)
 #pragma unroll

@@ -4,7 +4,7 @@ sys.path.insert(0, "/root/repo")
 from baryonyx_amd import _ffi, synth
 from baryonyx_amd.driver import compute_delta, normalize_costs
 from baryonyx_amd.util import pack_bits
-_ffi.LIB_PATH = os.path.join(_ffi.CSRC, "libbxh_tl.so")
+_ffi.LIB_PATH = os.path.join(_ffi.CSRC, os.environ.get("BXH_TL_LIB", "libbxh_tl.so"))
 os.environ.pop("BXH_LIB", None)
 L = _ffi.lib()
 L.bxh_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
