@@ -3506,10 +3506,14 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             const int* col_w = col_b + buf * RO;
             short* em = map_b + buf * pb.rmax;
             if (smode) { // consecutive rows: late = the column's neighbour is at most D rows away
+                // (not in the first row of the walk: nothing was loaded ahead for it.  A neighbour in
+                // a row in front of the walk's first makes a column of the second row late, which is
+                // safe: the chain sums it, and patches only from a row it has walked.)
                 const int2* cs_w = cs_b + buf * RO;
+                const int reach = q_ >= 2 ? D : 0;
                 for (int l = tid; l < r_; l += T) {
                     const int g = (cs_w[l].y >> (smode == 1 ? 24 : 28)) & 15;
-                    em[l] = (g >= 1 && g <= D) ? (short)-1 : (short)l;
+                    em[l] = (g >= 1 && g <= reach) ? (short)-1 : (short)l;
                 }
                 return;
             }
@@ -3725,7 +3729,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
                     // previous row of the walk, one slot up / down the column)
                     const unsigned w = (unsigned)recw;
                     const int g = (int)(smode == 1 ? w & 15u : (w >> 4) & 15u);
-                    late = g >= 1 && g <= D;
+                    late = g >= 1 && g <= D && q_ >= 2; // (the first row of a walk has nothing loaded ahead)
                     if (g == 1 && q_ >= 2) {
                         ml = (int)((smode == 1 ? w >> 8 : w >> 18) & 1023u);
                         ppos = ownpos + (smode == 1 ? -1 : 1);

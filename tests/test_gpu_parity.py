@@ -124,6 +124,56 @@ def test_long_pm1_rows_with_push_sweeps(oracle, bxh, groups, float_type, monkeyp
              expect_form=44 if groups == "p4" else None)
 
 
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("groups", ["4", "p4"])
+def test_consecutive_rows_starting_inside_the_matrix(oracle, bxh, order, groups, monkeypatch):
+    """The pipelined sweep takes the late columns of a row from static gaps when the row list is
+    a run of consecutive rows.  Here the run starts at row 12: the rows 0 .. 11
+    all hold one extra column that is set in x0, so they start satisfied and rows 12 .. m-1 are
+    the list -- the first rows of the walk have column neighbours in rows that are NOT walked
+    (late by the static rule, with no previous row to patch from), in both directions."""
+    monkeypatch.setenv("BXH_GROUPS", groups)
+    base = synth.make_scp(90, 700, 0.12, "real", 71)
+    rows = [list(base.col[base.row_ptr[k]:base.row_ptr[k + 1]]) for k in range(base.m)]
+    extra = base.n  # a new column, first in the rows 0 .. 11
+    for k in range(12):
+        rows[k] = [extra] + rows[k]
+    row_ptr = np.zeros(base.m + 1, np.int32)
+    row_ptr[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate([np.asarray(r, np.int32) for r in rows])
+    inst = synth.Instance(m=base.m, n=base.n + 1, row_ptr=row_ptr, col=col,
+                          factor=np.ones(col.shape[0], np.int32), cmin=base.cmin, cmax=base.cmax,
+                          obj_var=np.arange(base.n + 1, dtype=np.int32),
+                          obj_factor=np.concatenate([base.obj_factor, [3.25]]), maximize=False, kind=1,
+                          name="scp-run-from-12")
+
+    theta = 0.5
+    orc = oracle.Solver(inst, float_type=1, sort_mode=1, cost_norm=4, seed=5)
+    dev = bxh.DeviceBatch(inst, orc.cost(), 2, float_type=1)
+    if groups == "p4":
+        assert dev.kernel_form == 44
+    delta = orc.compute_delta(theta)
+    x0 = np.zeros(orc.nwords, np.uint64)
+    x0[extra >> 6] |= np.uint64(1) << np.uint64(extra & 63)
+    orcs = [orc, oracle.Solver(inst, float_type=1, sort_mode=1, cost_norm=4, seed=6)]
+    for b, s in enumerate(orcs):
+        s.set_x(x0)
+        dev.set_x(b, x0)
+        dev.set_rng(b, s.rng)
+        s.order_init(order)
+    dev.order_init(order)
+    assert list(orcs[0].violated()) == list(range(12, inst.m))
+    for it in range(4):
+        st = dev.sweep(0.03 * it, delta, theta, order=order)
+        for b, s in enumerate(orcs):
+            r = s.sweep(0.03 * it, delta, theta)
+            assert st["remaining"][b] == r
+            assert np.array_equal(dev.get_x(b), s.get_x())
+            assert bits_equal(dev.get_pi(b), s.get_pi()) and bits_equal(dev.get_P(b), s.get_P())
+            assert st["rng"][b] == s.rng
+    dev.close()
+
+
 ORDER_CASES = [
     # (name, maker, float_type, maximize, order, x0_density, push_at)
     ("infeas-decr-pm1", lambda: synth.make_pm1(50, 250, 0.06, "int", 41), 1, False, 3, 0.3, (5, 9)),
