@@ -4287,10 +4287,16 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             // between the loads below for loads "pending" from the last row.)
             __builtin_amdgcn_s_waitcnt(0x0f70);
             if (it + 1 < nrows && wave < SW) {
+                // (an opaque copy of the wave index: what the loads below derive from it is then
+                // worked out here, in three instructions -- kept across the row as loop invariants,
+                // two of those values were spilled and came back through `s_waitcnt vmcnt(0)`, one
+                // behind the other, in front of the very loads this row's top waits for)
+                int wv = wave;
+                asm volatile("" : "+v"(wv));
                 const int nl1 = misc_s[MS_LCNT + (cur ^ 1)];
-                if (wave * CW < nl1)
-                    issue_m(cs_b + (cur ^ 1) * RO, map_b + (cur ^ 1) * pb.rmax, nl1, wave,
-                            __builtin_amdgcn_readfirstlane(lnp_b[(cur ^ 1) * LNPW + wave]), CuScope{});
+                if (wv * CW < nl1)
+                    issue_m(cs_b + (cur ^ 1) * RO, map_b + (cur ^ 1) * pb.rmax, nl1, wv,
+                            __builtin_amdgcn_readfirstlane(lnp_b[(cur ^ 1) * LNPW + wv]), CuScope{});
             }
             // every thread has waited for its loads, and with them for the P
             // entries it stored in the previous row: that row is finished for
