@@ -1453,6 +1453,9 @@ bxh_create(const bxh_problem* pb,
     dp.lookahead = h->lookahead;
     dp.sw_chain = h->sw_chain;
     dp.sw_prod = h->sw_prod;
+    dp.static_late = 1;
+    if (const char* es = std::getenv("BXH_STATIC_LATE")) // (diagnostic: 0 keeps the column marks on every row list)
+        dp.static_late = std::atoi(es) != 0;
     dp.gather_other = 256;
     if (const char* eo = std::getenv("BXH_PIPE_GATHER"))
         dp.gather_other = std::max(0, std::atoi(eo));

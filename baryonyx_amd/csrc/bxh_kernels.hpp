@@ -37,6 +37,7 @@ struct DevProblem
     int lookahead; // pipelined sweep: a producer works on the row D positions past the last finished one
     int sw_chain, sw_prod; // pipelined sweep: waves with staging slots in the chain / a producer
     int gather_other; // pipelined sweep: entries of a row whose values the chain's non-staging waves fetch
+    int static_late;  // pipelined sweep: 1 = late columns of consecutive rows from the static gaps (0: always the marks)
     int cmax;     // longest column (real entries)
     int kind;     // bxh_kind
     int maximize; // 0 / 1
@@ -2880,7 +2881,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
     // look-up of the previous row's entry.  smode 1: ascending, 2: descending, 0: any other
     // list (the marks).  Chain and producers decide alike: they walk the same list.
     int smode = 0;
-    if (PIPE && (ord == 0 || ord == 1)) {
+    if (PIPE && pb.static_late && (ord == 0 || ord == 1)) {
         int bad = 0;
         for (int i = tid; i + 1 < nrows; i += T)
             bad |= (vrows[i + 1] - vrows[i] != 1);

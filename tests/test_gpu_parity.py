@@ -98,6 +98,18 @@ def test_sweeps_match_oracle_lane_per_column_kernel(oracle, bxh, case, monkeypat
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
 
 
+def test_scpnrh_shaped_rows_with_column_marks(oracle, bxh, monkeypatch):
+    """The pipelined sweep classifies the rows of a consecutive list from static gaps; any other
+    list, and every list with BXH_STATIC_LATE=0, goes by the column marks.  Full sweeps of the
+    bench shape's rows through the marks (what rounds 1 - 2 ran everywhere)."""
+    monkeypatch.setenv("BXH_GROUPS", "p4")
+    monkeypatch.setenv("BXH_STATIC_LATE", "0")
+    inst = synth.make_scp(120, 10000, 0.05, "int", 31)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=4, push_at=(2,), expect_form=44)
+    inst = synth.make_scp(100, 6000, 0.08, "real", 33)
+    run_case(oracle, bxh, inst, 1, False, 1, 0.0, batch=2, sweeps=3, push_at=(), expect_form=44)
+
+
 @pytest.mark.parametrize("groups", ["1", "4", "p4"])
 def test_scpnrh_shaped_rows(oracle, bxh, groups, monkeypatch):
     """Rows of ~500 elements and columns of ~50 (the bench shape, fewer rows):
