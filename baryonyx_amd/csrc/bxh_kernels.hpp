@@ -1740,6 +1740,21 @@ enum ZKind : int // :73-80
     Z_LINEAR = 4
 };
 
+// Node stack of branch_and_bound_solver (branch-and-bound-solver.hpp:195-536)
+// : per node a 0/1 vector (bit set), the sums and the level.  In LDS when it is small
+// (Z_SCRATCH_LDS; rows of up to a few hundred elements), else in global memory: the search is one
+// thread walking it word by word, a global round trip per word.
+__host__ __device__ inline size_t
+zscratch_size(int rmax, int fsize)
+{
+    const size_t words = static_cast<size_t>((rmax + 31) / 32);
+    const size_t depth = static_cast<size_t>(rmax) + 2;
+    // vars[depth][words] + solution[words] + sumr[depth] + sumf[depth] + level[depth]
+    return (depth + 1) * words * 4 + depth * (static_cast<size_t>(fsize) + 8) + 64;
+}
+
+constexpr int Z_SCRATCH_LDS = 16 * 1024;
+
 // LDS of the Z kernel: the plan of the lane-per-column kernel, then the
 // factor of every R position and a 0/1 result per position.
 __host__ __device__ inline int
@@ -1750,19 +1765,9 @@ lds_bytes_z(int m, int nwords, int rmax, int fsize)
     // + factor and 0/1 result per R position, + the sorted runs of
     // run_merge_sort, + the row's descriptors {first slot, padded length,
     // own slot, column} by row-local id
+    const int zs = (int)((zscratch_size(rmax, fsize) + 15) & ~(size_t)15);
     return lp.total + 2 * (((rmax + 1) * 4 + 15) & ~15) + ((n2 * 8 + 15) & ~15) +
-           ((n2 * 4 + 15) & ~15) + ((rmax * 16 + 15) & ~15);
-}
-
-// Node stack of branch_and_bound_solver (branch-and-bound-solver.hpp:195-536)
-// in global memory: per node a 0/1 vector (bit set), the sums and the level.
-__host__ __device__ inline size_t
-zscratch_size(int rmax, int fsize)
-{
-    const size_t words = static_cast<size_t>((rmax + 31) / 32);
-    const size_t depth = static_cast<size_t>(rmax) + 2;
-    // vars[depth][words] + solution[words] + sumr[depth] + sumf[depth] + level[depth]
-    return (depth + 1) * words * 4 + depth * (static_cast<size_t>(fsize) + 8) + 64;
+           ((n2 * 4 + 15) & ~15) + ((rmax * 16 + 15) & ~15) + (zs <= Z_SCRATCH_LDS ? zs : 0);
 }
 
 // One thread: the depth-first search of branch_and_bound_solver::solve
@@ -1938,7 +1943,11 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     int* vlist = use_m ? st.mrun + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
     int* out_list = keep ? st.slist + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
     const Float* cost = (const Float*)pb.cost;
-    unsigned char* scratch = st.zscratch + (size_t)inst * st.zscratch_bytes;
+    // (the node stack of the branch-and-bound rows: behind the descriptors in LDS when small)
+    const int zs_bytes = (int)((zscratch_size(pb.rmax, (int)sizeof(Float)) + 15) & ~(size_t)15);
+    unsigned char* scratch = zs_bytes <= Z_SCRATCH_LDS
+                               ? (unsigned char*)desc_s + ((pb.rmax * 16 + 15) & ~15)
+                               : st.zscratch + (size_t)inst * st.zscratch_bytes;
     unsigned* const err_word = st.cnt + 2 * gridDim.x;
 
     const Float kappa = (Float)a.kappa[inst];
