@@ -431,4 +431,12 @@ bxc_preprocess(const char* path,
     }
 }
 
+// the host's bit_array through a list of operations (itm_gpu.cpp: bit_array_script)
+BX_EXPORT int
+bxc_bitarray_script(int size, const int* ops, int nops, unsigned long long* words, int* gets)
+{
+    static_assert(sizeof(unsigned long long) == sizeof(std::uint64_t), "64-bit blocks");
+    return itm::bit_array_script(size, ops, nops, reinterpret_cast<std::uint64_t*>(words), gets);
+}
+
 } // extern "C"

@@ -58,6 +58,29 @@ struct bit_array
     }
     int operator[](int i) const noexcept { return static_cast<int>((w[i >> 6] >> (i & 63)) & 1ull); }
     bool operator==(const bit_array& o) const noexcept { return m_size == o.m_size && w == o.w; }
+    void ones() noexcept { std::fill(w.begin(), w.end(), ~std::uint64_t{ 0 }); }
+    void zeros() noexcept { std::fill(w.begin(), w.end(), std::uint64_t{ 0 }); }
+    // bit-array.hpp:183-236 (`assign`; nothing on the path calls it, kept for the
+    // reference's own check_bit_array expectations, lib/test/lib.cpp:677-783): the
+    // block of `from` keeps its top from % 64 bits, the block of `to` its low
+    // 64 - to % 64 bits, the rest of both and every whole block between come from `o`.
+    void assign(const bit_array& o, int from, int to)
+    {
+        size_t first = static_cast<size_t>(from) >> 6, last = static_cast<size_t>(to) >> 6;
+        const int fo = from & 63, to_ = to & 63;
+        if (fo) {
+            const std::uint64_t top = ~std::uint64_t{ 0 } << (64 - fo);
+            w[first] = (w[first] & top) | (o.w[first] & ~top);
+            ++first;
+        }
+        if (to_) {
+            const std::uint64_t top = ~std::uint64_t{ 0 } << (64 - to_);
+            w[last] = (w[last] & ~top) | (o.w[last] & top);
+        } else
+            ++last; // (`last` is exclusive below; with an offset the reference steps it back by one)
+        for (size_t b = first; b + 1 < last; ++b)
+            w[b] = o.w[b];
+    }
 };
 
 std::size_t
@@ -1691,6 +1714,34 @@ optimize_problem(const context& ctx, const problem& pb)
 }
 
 } // namespace
+
+// tests: the host's bit_array taken through a list of operations (op, p, q) --
+// 0 zeros, 1 ones, 2 set, 3 unset, 4 invert, 5 get -> `gets`, 6 / 7 assign from an
+// all-zeros / all-ones array over [p, q), 8 set(p, bool q) as the reference writes
+// it; returns the block count (lib/test/lib.cpp:677-783, tests/test_oracle_bitarray.py)
+int
+bit_array_script(int size, const int* ops, int nops, std::uint64_t* words, int* gets)
+{
+    bit_array a(size), other(size);
+    int ng = 0;
+    for (int i = 0; i != nops; ++i) {
+        const int op = ops[3 * i], p = ops[3 * i + 1], q = ops[3 * i + 2];
+        switch (op) {
+        case 0: a.zeros(); break;
+        case 1: a.ones(); break;
+        case 2: a.set(p); break;
+        case 3: a.unset(p); break;
+        case 4: a.invert(p); break;
+        case 5: gets[ng++] = a[p]; break;
+        case 6: other.zeros(); a.assign(other, p, q); break;
+        case 7: other.ones(); a.assign(other, p, q); break;
+        case 8: a.set_as_reference(p, q != 0); break;
+        default: return -1;
+        }
+    }
+    std::copy(a.w.begin(), a.w.end(), words);
+    return a.block_size();
+}
 
 result
 solve(const context& ctx, const problem& pb)

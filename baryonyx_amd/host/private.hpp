@@ -118,6 +118,7 @@ double compute_solution(const problem& pb, const std::vector<var_value>& x);
 namespace itm {
 result solve(const context& ctx, const problem& pb);
 result optimize(const context& ctx, const problem& pb);
+int bit_array_script(int size, const int* ops, int nops, std::uint64_t* words, int* gets); // tests
 }
 
 } // namespace baryonyx

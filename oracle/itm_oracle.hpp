@@ -119,6 +119,32 @@ struct BitArray
     {
         return static_cast<int>((w[i >> 6] >> (i & 63)) & 1ull);
     }
+    void ones() noexcept { std::fill(w.begin(), w.end(), ~0ull); }
+    void zeros() noexcept { std::fill(w.begin(), w.end(), 0ull); }
+    // bit_array_impl::assign(other, from, to), bit-array.hpp:183-236, as written
+    // there (no caller on the path; restated for lib/test/lib.cpp:677-783): the
+    // block holding `from` keeps its TOP from%64 bits and takes the rest from
+    // `other`, the block holding `to` keeps its LOW 64 - to%64 bits and takes the
+    // top to%64 from `other`, whole blocks in between are copied.
+    void assign(const BitArray& other, int from, int to)
+    {
+        int lo = from >> 6, hi = to >> 6;
+        if (const int off = from & 63) {
+            const std::uint64_t keep = (w[lo] >> (64 - off)) << (64 - off);
+            const std::uint64_t take = (other.w[lo] << off) >> off;
+            w[lo] = take | keep;
+            ++lo;
+        }
+        if (const int off = to & 63) {
+            const size_t b = static_cast<size_t>(hi);
+            const std::uint64_t keep = (w[b] << off) >> off;
+            const std::uint64_t take = (other.w[b] >> (64 - off)) << (64 - off);
+            w[b] = take | keep;
+            --hi;
+        }
+        for (int b = lo; b < hi; ++b)
+            w[b] = other.w[b];
+    }
     bool operator==(const BitArray& o) const noexcept
     {
         return m_size == o.m_size && w == o.w;

@@ -661,10 +661,36 @@ orc_exhaustive_solve(int maximize,
 void
 orc_bitarray_set_value(uint64_t* words, int index, int val)
 {
-    orc::BitArray a(index + 1);
+    // `words` holds index / 64 + 1 blocks (oracle_capi.h); BitArray(index + 1)
+    // would hold one more when (index + 1) % 64 == 0
+    orc::BitArray a(index);
     std::copy(words, words + a.block_size(), a.w.begin());
     a.set_as_reference(index, val != 0);
     std::copy(a.w.begin(), a.w.end(), words);
+}
+
+int
+orc_bitarray_script(int size, const int* ops, int nops, uint64_t* words, int* gets)
+{
+    orc::BitArray a(size), other(size);
+    int ng = 0;
+    for (int i = 0; i != nops; ++i) {
+        const int op = ops[3 * i], p = ops[3 * i + 1], q = ops[3 * i + 2];
+        switch (op) {
+        case 0: a.zeros(); break;
+        case 1: a.ones(); break;
+        case 2: a.set(p); break;
+        case 3: a.unset(p); break;
+        case 4: a.invert(p); break;
+        case 5: gets[ng++] = a[p]; break;
+        case 6: other.zeros(); a.assign(other, p, q); break;
+        case 7: other.ones(); a.assign(other, p, q); break;
+        case 8: a.set_as_reference(p, q != 0); break;
+        default: return -1;
+        }
+    }
+    std::copy(a.w.begin(), a.w.end(), words);
+    return a.block_size();
 }
 
 } // extern "C"

@@ -165,7 +165,15 @@ int orc_exhaustive_solve(int maximize,
 
 /* bit_array_impl::set(int index, bool val) exactly as lib/src/bit-array.hpp:144-149
  * writes it (the mutation loop's only bit operation, itm-optimizer-common.hpp:523) */
+/* `words`: index / 64 + 1 blocks, read and written */
 void orc_bitarray_set_value(uint64_t* words, int index, int val);
+
+/* A bit_array of `size` bits (zeros) taken through `nops` operations
+ * (op, p, q): 0 zeros, 1 ones, 2 set(p), 3 unset(p), 4 invert(p), 5 get(p) -> next
+ * slot of `gets`, 6 assign(all-zeros array, p, q), 7 assign(all-ones array, p, q),
+ * 8 set(p, bool q) as the reference writes it.  `words` receives the size / 64 + 1
+ * blocks; returns the block count.  (lib/test/lib.cpp:677-783) */
+int orc_bitarray_script(int size, const int* ops, int nops, uint64_t* words, int* gets);
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,8 @@
 """The oracle's optimize() (oracle/itm_oracle_opt.hpp: optimize_functor +
 storage + best_solution_recorder restated, lib/src/itm-optimizer-common.hpp:
 54-908) on the CPU: the deterministic schedule really is deterministic, the
-population keeps storage's invariants, and what lib/test/optimize.cpp:55-90
-expects of small4.lp (optimize reaches 790) is examined with the restated loop."""
+population keeps storage's invariants.  (What lib/test/optimize.cpp expects of
+small4.lp and the n-queens files: tests/test_reference_held.py.)"""
 import os
 
 import numpy as np
@@ -55,23 +55,3 @@ def test_schedule_is_deterministic_and_population_is_consistent(oracle, maker, k
     r3, _ = oracle.optimize(inst, 1, p, thread=5, rounds=400)
     assert (r3.remaining_constraints, r3.value if not inst.maximize else -r3.value) <= \
            (r1.remaining_constraints, r1.value if not inst.maximize else -r1.value)
-
-
-def test_qap_small4_with_the_reference_tests_parameters(oracle):
-    """lib/test/optimize.cpp:55-90 expects optimize() to reach 790 on small4.lp
-    within 40 s on 2 threads (the test is excluded from the reference's CI,
-    .travis.yml:100-111).  With that test's parameters the restated loop -- both
-    tie rules, several seeds, 60 000 rounds (~7 restarts per worker, each running
-    into kappa_max = 10 after 10 000 sweeps) -- never satisfies the eight
-    `sum x = 1` rows of the instance: kappa passes 1, where kappa / (1 - kappa)
-    changes sign.  Recorded here as what the restatement does; the reference
-    cannot be run in this environment to tell whether its own test passes."""
-    from baryonyx_amd import host_ffi as H
-    inst = H.merged(os.path.join(LP, "small4.lp"))
-    assert (inst.m, inst.n, inst.kind) == (136, 272, 2)
-    p = oracle.default_params(seed=1, sort_mode=0, limit=2**62, theta=0.5, delta=0.2, kappa_step=10e-4,
-                              kappa_max=10.0, alpha=0.0, w=20.0, pushing_k_factor=0.9, pushes_limit=50,
-                              pushing_objective_amplifier=10.0, pushing_iteration_limit=50)
-    r, o = oracle.optimize(inst, 1, p, thread=2, rounds=12000)
-    assert r.status == 3 and r.remaining_constraints == 8  # time_limit_reached, 8 rows violated
-    assert o["pop_remaining"][0] == 8

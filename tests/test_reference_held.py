@@ -1,0 +1,359 @@
+"""CPU: every expectation the reference's own solver tests hold for the path,
+restated against the ORACLE (lib/test/solve.cpp, lib/test/optimize.cpp; the
+reference's test runner, boost.ut, is an empty submodule and the library cannot
+be built here).  The same cases run against the HIP path
+through <baryonyx/core> in tests/test_gpu_reference_held.py (a compiled C++
+client, tests/cpp/client_reference.cpp).
+
+The reference seeds from the clock (solver_parameters::seed = 0,
+itm-common.hpp:1448-1451) wherever its tests do not set one, i.e. its
+expectations are meant for any seed: every case runs with the seeds below.
+Parameters go through context_set_solver_parameters' range checks
+(lib/src/private.cpp:50-172, helpers.validated_params): a kappa triple whose
+kappa_max is above 1 is dropped as a whole, `limit = -1` means no limit (capped
+here), `w` is a sweep count.
+
+Expectations that are NOT reproduced are listed at the end of the file with
+the trace that explains each."""
+import os
+
+import numpy as np
+import pytest
+
+from baryonyx_amd import host_ffi as H
+from helpers import is_feasible, objective, oracle_params, validated_params, x_bits
+
+LP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lp")
+SEEDS = [1, 2, 123456789]
+CAP = 200000
+
+# ----------------------------------------------------------------- inline LPs
+REAL_COST = """minimize
+- 0.1 a - 0.5 b - 0.9 c - 1e-7 d
+Subject to:
+-a -b -c <= -1
+-a -b -c >= -3
+-a -c >= -2
+-a -c <= -1
+a + c >= 1
++ b + c +d >= 2
+Binaries
+a b c d
+End
+"""  # lib/test/solve.cpp:261-290 (test_real_cost)
+
+NEGATIVE_COEFF5 = REAL_COST.replace("- 0.1 a - 0.5 b - 0.9 c - 1e-7 d", "a b c d")  # :404-429
+
+QUADRATIC_PREPROCESSOR = """minimize
+-5a + [ 2a * b + 3c * d ] /2 + 10b
+Subject to:
+a + b >= 0
+b + c + d >= 0
+Binaries
+a b c d
+End
+"""  # :242-259
+
+Z_COEFFICIENT_A = """minimize
+15 x1 + 19 x2 + 13 x3 + 12 x4
+Subject to:
+2 x1 + 1 x2 + 3 x3 + 2 x4 <= 3
+Binaries
+x1 x2 x3 x4
+End
+"""  # :596-616
+
+Z_COEFFICIENT_B = """minimize
+Subject to:
+2a + 3b -5c + 7d <= 0
+-2b + 2c >= 1
+7a + 7d <= 7
+Binaries
+a b c d
+End
+"""  # :618-638
+
+
+def drawn_costs(draw, count):
+    """Uniform-looking integer costs in 1..100 (the reference draws them from
+    std::random_device); the same rule as tests/cpp/client_reference.cpp."""
+    return np.array([1 + ((draw + 1) * 7919 + i * 104729 + i * i * 31) % 100 for i in range(count)], np.float64)
+
+
+def _merged_text(tmp_path, text, name="inline.lp"):
+    path = str(tmp_path / name)
+    with open(path, "w") as f:
+        f.write(text)
+    return path, H.merged(path)
+
+
+def _solve(oracle, inst, seed, sort_mode=1, cap=CAP, **raw):
+    p = oracle_params(oracle, cap=cap, sort_mode=sort_mode, seed=seed, **raw)
+    return oracle.solve(inst, 1, p)
+
+
+def _expect_success_and_valid(inst, res, xw):
+    assert res.status == 0, f"status {res.status}, remaining {res.remaining_constraints}"
+    assert is_feasible(inst, xw)
+    assert res.value == objective(inst, xw)
+
+
+# ------------------------------------------------------ lib/test/solve.cpp
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("which", ["a", "b"])
+def test_Z_coefficient_1(oracle, tmp_path, which, seed):
+    """solve.cpp:596-639 -- the reference's only end-to-end tests of the
+    inequalities-Z solver: status == success and a valid point, default
+    parameters, for both inline problems."""
+    _, inst = _merged_text(tmp_path, Z_COEFFICIENT_A if which == "a" else Z_COEFFICIENT_B)
+    if inst.m == 0:  # the preprocessor may settle the whole instance
+        return
+    assert inst.kind == 4
+    res, xw = _solve(oracle, inst, seed)
+    _expect_success_and_valid(inst, res, xw)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_real_cost(oracle, tmp_path, seed):
+    """solve.cpp:261-290: success, a valid point, value < 0."""
+    _, inst = _merged_text(tmp_path, REAL_COST)
+    if inst.m == 0:
+        assert inst.obj_constant < 0.0
+        return
+    res, xw = _solve(oracle, inst, seed)
+    _expect_success_and_valid(inst, res, xw)
+    assert res.value < 0.0
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_negative_coeff5(oracle, tmp_path, seed):
+    """solve.cpp:404-429: success and a valid point."""
+    _, inst = _merged_text(tmp_path, NEGATIVE_COEFF5)
+    if inst.m == 0:
+        return
+    res, xw = _solve(oracle, inst, seed)
+    _expect_success_and_valid(inst, res, xw)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_quadratic_preprocessor(oracle, tmp_path, seed):
+    """solve.cpp:242-259: the problem parses and solve() returns a solution."""
+    path, inst = _merged_text(tmp_path, QUADRATIC_PREPROCESSOR)
+    assert H.parse(path).status == 0
+    if inst.m == 0:
+        return
+    res, xw = _solve(oracle, inst, seed)
+    assert res.status == 0 and is_feasible(inst, xw)
+
+
+def test_preprocessor_on_prepro_lp(oracle):
+    """solve.cpp:77-193 (test_preprocessor): prepro.lp, cost_norm = loo.  The
+    preprocessor fixes 21 variables and leaves 2 (host logic, pinned value by value
+    in tests/test_gpu_reference_held.py through result.affected_vars); what the
+    solver sees must come out success + valid, and the whole problem's value is
+    above 6."""
+    pp = H.preprocess(os.path.join(LP, "prepro.lp"))
+    assert pp["info"].affected == 21 and pp["info"].variables == 2
+    inst = H.merged(os.path.join(LP, "prepro.lp"))
+    assert inst.n == 2
+    for seed in SEEDS:
+        res, xw = _solve(oracle, inst, seed, cost_norm=4)
+        _expect_success_and_valid(inst, res, xw)
+        assert res.value > 6.0
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_assignment_problem(oracle, seed):
+    """solve.cpp:292-303: success with the default parameters."""
+    inst = H.merged(os.path.join(LP, "assignment_problem_1.lp"))
+    res, xw = _solve(oracle, inst, seed)
+    _expect_success_and_valid(inst, res, xw)
+
+
+RANDOM_COST_PARAMS = dict(limit=1000000, theta=0.5, delta=0.2, kappa_step=10e-4, kappa_max=10.0,
+                          alpha=0.0, w=20)  # solve.cpp:307-315 (kappa triple dropped: 10 > 1)
+
+
+@pytest.mark.parametrize("draw", range(10))
+def test_assignment_problem_random_cost(oracle, draw):
+    """solve.cpp:305-335: ten draws of uniform integer costs in 1..100 on
+    assignment_problem_1.lp (the reference draws them from std::random_device;
+    a fixed rule here): success and a valid point every time."""
+    inst = H.merged(os.path.join(LP, "assignment_problem_1.lp"))
+    inst.obj_factor = drawn_costs(draw, len(inst.obj_factor))
+    res, xw = _solve(oracle, inst, 1 + draw, **RANDOM_COST_PARAMS)
+    _expect_success_and_valid(inst, res, xw)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("name,raw", [
+    ("negative-coeff.lp", dict(limit=50)),      # :337-351
+    ("negative-coeff2.lp", dict()),             # :353-369
+    ("negative-coeff3.lp", dict(limit=10000)),  # :371-386
+    ("negative-coeff4.lp", dict(limit=50)),     # :388-402
+])
+def test_negative_coeff_files(oracle, name, raw, seed):
+    inst = H.merged(os.path.join(LP, name))
+    if inst.m == 0:
+        return
+    res, xw = _solve(oracle, inst, seed, **raw)
+    _expect_success_and_valid(inst, res, xw)
+
+
+def test_negative_coeff2_variable_count():
+    """solve.cpp:367-368: affected + remaining variables == 4."""
+    pp = H.preprocess(os.path.join(LP, "negative-coeff2.lp"))
+    assert pp["info"].affected + pp["info"].variables == 4
+
+
+QUEENS_PARAMS = dict(limit=-1, theta=0.5, delta=0.02, kappa_step=0.01, kappa_max=60.0, alpha=1.0,
+                     w=40)  # solve.cpp:437-445 (kappa triple dropped: 60 > 1)
+QUEENS_FIXED_COST = [25, 89, 12, 22, 84, 3, 61, 14, 93, 97, 68, 5, 51, 72, 96, 80, 13, 38, 81, 48, 70, 50,
+                     66, 68, 30, 97, 79, 4, 41, 44, 47, 62, 60, 11, 18, 44, 57, 24, 7, 11, 66, 87, 9, 17,
+                     27, 60, 95, 45, 94, 47, 60, 87, 79, 53, 81, 52, 91, 53, 57, 8, 63, 78, 1, 8]  # :448-453
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_8_queens_puzzle_fixed_cost(oracle, seed):
+    """solve.cpp:431-474."""
+    inst = H.merged(os.path.join(LP, "8_queens_puzzle.lp"))
+    assert len(inst.obj_factor) == 64
+    inst.obj_factor = np.array(QUEENS_FIXED_COST, np.float64)
+    res, xw = _solve(oracle, inst, seed, **QUEENS_PARAMS)
+    _expect_success_and_valid(inst, res, xw)
+    assert int(x_bits(xw, inst.n).sum()) == 8
+
+
+@pytest.mark.parametrize("draw", range(10))
+def test_8_queens_puzzle_random_cost(oracle, draw):
+    """solve.cpp:476-508: order = infeasibility_decr, ten cost draws."""
+    inst = H.merged(os.path.join(LP, "8_queens_puzzle.lp"))
+    inst.obj_factor = drawn_costs(draw, len(inst.obj_factor))
+    res, xw = _solve(oracle, inst, 1 + draw, order=3, **QUEENS_PARAMS)
+    _expect_success_and_valid(inst, res, xw)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_qap_solve_is_valid_when_it_succeeds(oracle, seed):
+    """solve.cpp:510-529: `if (result) expect(is_valid_solution)` -- the
+    reference's own solve() test of small4.lp does NOT expect success."""
+    inst = H.merged(os.path.join(LP, "small4.lp"))
+    res, xw = _solve(oracle, inst, seed, cap=20000, limit=-1, theta=0.5, delta=0.01, kappa_step=10e-4,
+                     kappa_max=10.0, alpha=0.0, w=20)
+    if res.status == 0:
+        assert is_feasible(inst, xw)
+    else:
+        assert res.remaining_constraints > 0
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("name,raw", [
+    ("flat30-7.lp", dict(limit=-1, delta=0.001, kappa_min=0.3, kappa_step=1e-10, kappa_max=1.0,
+                         order=1)),                                                     # :531-549
+    ("uf50-0448.lp", dict(limit=-1, theta=0.5, delta=1.0, kappa_min=0.1, kappa_step=1e-17,
+                          kappa_max=1.0, alpha=2.0, w=60, order=2)),                    # :551-572
+    ("aim-50-1_6-yes1-2.lp", dict(limit=-1, theta=0.6, delta=0.01, kappa_step=2 * 10e-4,
+                                  kappa_max=100.0, alpha=1.0, w=20)),                   # :574-593
+])
+def test_sat_files(oracle, name, raw, seed):
+    inst = H.merged(os.path.join(LP, name))
+    res, xw = _solve(oracle, inst, seed, **raw)
+    _expect_success_and_valid(inst, res, xw)
+
+
+# --------------------------------------------------- lib/test/optimize.cpp
+NQUEENS_PARAMS = dict(limit=100000, theta=0.5, delta=1.0, kappa_min=0.30, kappa_step=1e-2, kappa_max=100.0,
+                      alpha=1.0, w=60, pushing_k_factor=0.9, pushes_limit=50,
+                      pushing_objective_amplifier=10, pushing_iteration_limit=10,
+                      order=2)  # optimize.cpp:115-130 (kappa triple dropped: 100 > 1)
+
+
+def _cplex_values():
+    with open(os.path.join(LP, "n-queens", "solutions.txt")) as f:
+        return [float(t) for t in f.read().split()]
+
+
+def test_n_queens_problem(oracle):
+    """optimize.cpp:89-165: optimize() on the 30 n-queens files (20 s each in
+    the reference; a budget of lock-step rounds here) must find a valid point for
+    every file (`all_found == 30`).  The test's other line, `mean_distance >= 0`
+    with distance = (cplex - value) / cplex, is NOT asserted: the files minimise,
+    so it holds only if all 30 heuristic values EQUAL the CPLEX optima (note at
+    the end of the file)."""
+    cplex = _cplex_values()
+    assert len(cplex) == 30
+    q = validated_params(**NQUEENS_PARAMS)
+    assert (q["kappa_min"], q["kappa_step"], q["kappa_max"]) == (0.0, 1e-3, 0.6)
+    found = 0
+    for i in range(30):
+        inst = H.merged(os.path.join(LP, "n-queens", f"n-queens-problem-{i}.lp"))
+        assert (inst.kind, inst.maximize) == (1, False)
+        p = oracle_params(oracle, seed=100 + i, **NQUEENS_PARAMS)
+        res, out = oracle.optimize(inst, 1, p, thread=2, rounds=1500)
+        if res.remaining_constraints == 0:
+            assert res.status == 0 and is_feasible(inst, out["pop_x"][0])
+            assert res.value == objective(inst, out["pop_x"][0]) >= cplex[i]  # CPLEX's value is the optimum
+            found += 1
+    assert found == 30
+
+
+def test_qap_optimize_with_the_reference_tests_parameters(oracle):
+    """optimize.cpp:55-87 (test_qap) expects optimize() on small4.lp to return
+    `success` with value 790 within 40 s on 2 threads.  NOT reproduced: with that
+    test's parameters as the library validates them (kappa_max = 10 is out of
+    range, so 0 / 1e-3 / 0.6 stay; limit = -1 -> no limit; w = 20) the restated
+    loop ends every restart at kappa_max with rows still violated, and the
+    incumbent keeps the eight `sum x = 1` rows violated (x = 0).  See the note at
+    the end of this file and tests/test_oracle_handcheck.py."""
+    inst = H.merged(os.path.join(LP, "small4.lp"))
+    assert (inst.m, inst.n, inst.kind) == (136, 272, 2)
+    raw = dict(limit=-1, theta=0.5, delta=0.2, kappa_step=10e-4, kappa_max=10.0, alpha=0.0, w=20,
+               pushing_k_factor=0.9, pushes_limit=50, pushing_objective_amplifier=10,
+               pushing_iteration_limit=50)
+    q = validated_params(**raw)
+    assert (q["kappa_min"], q["kappa_step"], q["kappa_max"], q["w"], q["limit"]) == \
+           (0.0, 1e-3, 0.6, 20.0, 2 ** 63 - 1)
+    for sort_mode in (0, 1):
+        p = oracle_params(oracle, sort_mode=sort_mode, seed=1, **raw)
+        res, out = oracle.optimize(inst, 1, p, thread=2, rounds=12000)
+        assert res.status == 3 and res.remaining_constraints == 8  # time_limit_reached
+        assert out["pop_remaining"][0] == 8
+
+
+# ---------------------------------------------------------------------------
+# Reference-held expectations that are NOT asserted above, and why
+#
+# * optimize.cpp:77-79 `status == success`, `value == 790` on small4.lp.
+#   The instance is a linearised QAP: eight rows `sum_j x_ij = 1` over sixteen
+#   zero-cost x variables, and 128 rows `sum_l y_.. - x_ij = 0` in which x has
+#   the coefficient -1.  For a -1 coefficient the reference forms the reduced
+#   cost with `a * P` and negates it (itm-solver-equalities-101.cpp:178-188), and
+#   `affect` moves the preference of a SELECTED negated variable by `P -= d`
+#   (itm-common.hpp:404-413, 421-433, 445-455): r_x = c + pi_k + P_kx + ..., so
+#   R.value = -r_x RISES by d for the variable the row just selected -- the
+#   preference works against the row's own choice, for every -1 entry.  (NEWS,
+#   v0.3.3: "Fix the preference matrix assignment for both equalities and
+#   inequalities with -1 and 1 coefficients ... revert only the added or
+#   subtracted value" -- this code was rewritten after the test's parameters,
+#   kappa_max = 10, went out of range.)  tests/test_oracle_handcheck.py replays
+#   the first sweeps of small4 row by row with the reference's formulas written
+#   out in Python and finds the oracle bit-identical; the rows never close
+#   because each y row undoes what the x rows set (trace: tools/trace_small4.py).
+#   The reference's own solve() test of the same file, solve.cpp:526-528, guards
+#   its only assertion with `if (result)`: its authors do not expect success
+#   there either.  testoptimizer is excluded from the reference's CI
+#   (.travis.yml:100-111 `ctest -E testoptimizer`).
+# * solve.cpp:217 `value < 1156908` on capmo1_direct.lp (the print statement
+#   one line above says "== 6212977"): tests/test_oracle_fixtures.py
+#   ::test_capmo1_direct_default_solve keeps the three assertions that hold
+#   (success, valid, recomputed value) and documents the fourth.
+# * optimize.cpp:152-163 `mean_distance >= 0` over the n-queens files: a
+#   minimisation's feasible value is never below the optimum, so the sum of
+#   (cplex - value) / cplex is >= 0 only when every value is optimal.  The
+#   restated optimize() finds valid points for all 30 but not the optima (first
+#   solutions 5 - 60 % above; further restarts return to the same points because
+#   P and pi persist across restarts, itm-optimizer-common.hpp:649-663, and the
+#   01 solvers' push indexes the costs with the row-local id,
+#   itm-solver-inequalities-01.cpp:236-237).  Only `all_found` is asserted.
+# * optimize.cpp:40-53 (bibd1n.lp) runs mode = branch, the branch optimiser:
+#   out of scope.
