@@ -99,16 +99,18 @@ set_lds_limits(int device)
     if (device >= 0 && static_cast<size_t>(device) < done.size() && done[device])
         return hipSuccess;
     const int limit = 160 * 1024;
-    hipError_t e = hipSuccess;
-    // (a kernel's static LDS counts against the same 160 KiB)
+    // (a kernel's static LDS counts against the same 160 KiB.)  A refused call is
+    // not fatal here: the kernel keeps the 64 KiB default, which is all a small
+    // handle asks for; a handle whose plan needs more then fails at its launch,
+    // loudly (BXH_ERR_DEVICE), instead of every create on the device failing.
     auto raise = [&](const void* fn) {
-        if (e != hipSuccess)
-            return;
         hipFuncAttributes fa;
-        e = hipFuncGetAttributes(&fa, fn);
+        hipError_t e = hipFuncGetAttributes(&fa, fn);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     limit - static_cast<int>(fa.sharedSizeBytes));
+        if (e != hipSuccess)
+            (void)hipGetLastError();
     };
 #define BXH_SET_LDS(...) raise(reinterpret_cast<const void*>(&__VA_ARGS__))
     BXH_SET_LDS(bxh::sweep_kernel<float, false>);
@@ -198,8 +200,6 @@ set_lds_limits(int device)
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 3>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 4>);
 #undef BXH_SET_LDS
-    if (e != hipSuccess)
-        return e;
     if (device >= 0) {
         if (static_cast<size_t>(device) >= done.size())
             done.resize(static_cast<size_t>(device) + 1, 0);
@@ -1202,6 +1202,12 @@ bxh_create(const bxh_problem* pb,
         // column" is this static gap, and neither the chain nor the producers need their
         // column marks (bxh_kernels.hpp: smode).  w = up | down << 4 | index up << 8 | index
         // down << 18; the producers find the two gaps in bits 24 .. 31 of row_cs[e].y.
+        // (the two in-row indices take 10 bits each here, and the chain's merged mark is
+        // `code << 10 | index` in 16 bits: both need rows of at most 1024 elements, which is
+        // what the pipe gate above admits -- checked again where the packing depends on it)
+        static_assert(bxh::PIPE_RING <= 63, "the marks' code space is 6 bits (position mod 63 + 1)");
+        if (rmax > 1024)
+            return fail(BXH_ERR_UNSUPPORTED, "pipelined sweep: rows of more than 1024 elements");
         std::vector<unsigned> nb(static_cast<size_t>(nnz), 0u);
         {
             std::vector<int> last(static_cast<size_t>(n), -1); // last element seen in column j

@@ -58,8 +58,11 @@ struct DevProblem
                                //  CSC slot of the entry, column}: one load per entry
     const void* desc_cost;     // [nnz] Float: cost of the descriptor's column
     const int4* chain_rec;     // [nnz + 64] pipelined sweep, row chain: {first CSC slot, padded length |
-                               //  position of the entry in its column << 16, column, 0} of CSR element e:
-                               //  a row's records are one run, moved to LDS two rows ahead by LDS-DMA
+                               //  position of the entry in its column << 16, column, w} of CSR element e,
+                               //  w = rows up | rows down << 4 to the column's neighbouring entries (clipped
+                               //  to 15, 0 = none) | the neighbour's index in its row << 8 (up) / << 18 (down)
+                               //  where it is the adjacent row: a row's records are one run, moved to LDS
+                               //  two rows ahead by LDS-DMA
     const unsigned* ownmask;   // [groups][2*nwords] x bits of each owner
     const signed char* fac_csr; // [nnz]  coefficient of CSR element (101 kinds)
     // inequalities-Z (general integer coefficients)
@@ -1754,20 +1757,37 @@ zscratch_size(int rmax, int fsize)
 }
 
 constexpr int Z_SCRATCH_LDS = 16 * 1024;
+constexpr int Z_LDS_LIMIT = 160 * 1024; // the LDS of a gfx950 CU (bxh_device.hip: lds_limit)
 
 // LDS of the Z kernel: the plan of the lane-per-column kernel, then the
 // factor of every R position and a 0/1 result per position.
 __host__ __device__ inline int
-lds_bytes_z(int m, int nwords, int rmax, int fsize)
+lds_bytes_z_base(int m, int nwords, int rmax, int fsize)
 {
     const LdsPlan lp = lds_plan(m, nwords, rmax, fsize);
     const int n2 = next_pow2(rmax < 64 ? 64 : rmax); // whole 64-entry runs
     // + factor and 0/1 result per R position, + the sorted runs of
     // run_merge_sort, + the row's descriptors {first slot, padded length,
     // own slot, column} by row-local id
-    const int zs = (int)((zscratch_size(rmax, fsize) + 15) & ~(size_t)15);
     return lp.total + 2 * (((rmax + 1) * 4 + 15) & ~15) + ((n2 * 8 + 15) & ~15) +
-           ((n2 * 4 + 15) & ~15) + ((rmax * 16 + 15) & ~15) + (zs <= Z_SCRATCH_LDS ? zs : 0);
+           ((n2 * 4 + 15) & ~15) + ((rmax * 16 + 15) & ~15);
+}
+
+// The node stack sits in LDS only when it is small AND the plan still fits with
+// it; otherwise the kernel uses the per-instance global scratch (host and kernel
+// decide with this one function).
+__host__ __device__ inline bool
+z_stack_in_lds(int m, int nwords, int rmax, int fsize)
+{
+    const int zs = (int)((zscratch_size(rmax, fsize) + 15) & ~(size_t)15);
+    return zs <= Z_SCRATCH_LDS && lds_bytes_z_base(m, nwords, rmax, fsize) + zs <= Z_LDS_LIMIT;
+}
+
+__host__ __device__ inline int
+lds_bytes_z(int m, int nwords, int rmax, int fsize)
+{
+    const int zs = (int)((zscratch_size(rmax, fsize) + 15) & ~(size_t)15);
+    return lds_bytes_z_base(m, nwords, rmax, fsize) + (z_stack_in_lds(m, nwords, rmax, fsize) ? zs : 0);
 }
 
 // One thread: the depth-first search of branch_and_bound_solver::solve
@@ -1944,8 +1964,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     int* out_list = keep ? st.slist + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
     const Float* cost = (const Float*)pb.cost;
     // (the node stack of the branch-and-bound rows: behind the descriptors in LDS when small)
-    const int zs_bytes = (int)((zscratch_size(pb.rmax, (int)sizeof(Float)) + 15) & ~(size_t)15);
-    unsigned char* scratch = zs_bytes <= Z_SCRATCH_LDS
+    unsigned char* scratch = z_stack_in_lds(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float))
                                ? (unsigned char*)desc_s + ((pb.rmax * 16 + 15) & ~15)
                                : st.zscratch + (size_t)inst * st.zscratch_bytes;
     unsigned* const err_word = st.cnt + 2 * gridDim.x;

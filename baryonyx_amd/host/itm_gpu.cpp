@@ -553,11 +553,17 @@ struct device_pool
         bxh_status& operator[](int b) { return p.at[b].d->status[p.at[b].i]; }
     } status{ *this };
 
+    // `norm_costs`: one cost vector for every worker, or one PER WORKER (the random
+    // cost norm: optimize_functor normalises with the worker's own engine,
+    // itm-optimizer-common.hpp:633-638).  A handle holds one cost vector, so with
+    // per-worker costs every worker gets a handle of its own (batch 1, dealt round
+    // robin over the devices; the launches of a round still overlap, one stream each).
+    std::vector<double> delta_of; // per handle, when the workers' costs differ
     template<typename Float>
     device_pool(const context& ctx,
                 const std::vector<merged_constraint>& csts,
                 int variables,
-                const cost_type<Float>& norm_costs,
+                const std::vector<cost_type<Float>>& norm_costs,
                 int kind,
                 bool maximize,
                 int workers_)
@@ -566,11 +572,13 @@ struct device_pool
         std::vector<int> ids = ctx.devices.empty() ? std::vector<int>{ ctx.device } : ctx.devices;
         if (static_cast<int>(ids.size()) > workers)
             ids.resize(static_cast<size_t>(workers));
-        const int D = static_cast<int>(ids.size());
+        const bool own_costs = norm_costs.size() > 1;
+        const int D = own_costs ? workers : static_cast<int>(ids.size());
         for (int d = 0; d != D; ++d) {
             const int share = (workers - d + D - 1) / D; // workers d, d + D, ...
-            dev.emplace_back(std::make_unique<device_batch>(ctx, csts, variables, norm_costs, kind,
-                                                            maximize, share, ids[d]));
+            dev.emplace_back(std::make_unique<device_batch>(
+              ctx, csts, variables, norm_costs[own_costs ? static_cast<size_t>(d) : 0], kind, maximize, share,
+              ids[static_cast<size_t>(d) % ids.size()]));
         }
         for (int b = 0; b != workers; ++b)
             at.push_back(ref{ dev[static_cast<size_t>(b % D)].get(), b / D });
@@ -696,7 +704,7 @@ struct device_pool
             for (auto a : dev[d]->active)
                 any = any || a;
             if (any) {
-                dev[d]->sweep_async(delta, theta, push, obj_amp, order);
+                dev[d]->sweep_async(delta_of.empty() ? delta : delta_of[d], theta, push, obj_amp, order);
                 launched[d] = 1;
             }
         }
@@ -1414,14 +1422,6 @@ optimize_problem(const context& ctx, const problem& pb)
 
     // `thread` workers -> one batch of solver instances (64 when unset)
     const int workers = p.thread <= 0 ? 64 : p.thread;
-    // The random cost norm (itm-common.hpp:1221-1326) gives every worker of the
-    // reference its own cost vector, drawn from its own engine
-    // (optimize_functor::operator(), itm-optimizer-common.hpp:633-638).  One batch
-    // of instances shares one cost vector here: refuse rather than run something
-    // else.  (solve(), one instance, takes it.)
-    if (p.cost_norm == solver_parameters::cost_norm_type::random && workers > 1)
-        throw solver_failure(solver_error_tag::no_solver_available);
-
     recorder<Float> best_recorder(rng, workers, cost, cost_constant, variables, constraints,
                                   p.init_population_size, maximize);
     const auto seeds = generate_seed(rng, static_cast<unsigned>(workers));
@@ -1433,14 +1433,22 @@ optimize_problem(const context& ctx, const problem& pb)
 
     // optimize_functor::operator() prologue (:627-656), identical for every
     // worker except for the engine the random cost norm draws from
-    cost_type<Float> norm_costs(cost);
-    norm_costs.normalize(p.cost_norm, lctx[0].rng);
+    // (itm-optimizer-common.hpp:633-638, make_random_norm itm-common.hpp:1025-1075):
+    // with that norm every worker normalises with its own engine and so holds its
+    // own cost vector -- and its own automatic delta.
+    const bool own_costs = p.cost_norm == solver_parameters::cost_norm_type::random && workers > 1;
+    std::vector<cost_type<Float>> norm_costs_w(own_costs ? static_cast<size_t>(workers) : 1, cost);
+    for (size_t b = 0; b != norm_costs_w.size(); ++b)
+        norm_costs_w[b].normalize(p.cost_norm, lctx[b].rng);
+    const cost_type<Float>& norm_costs = norm_costs_w[0];
     const auto kappa_step = static_cast<Float>(p.kappa_step);
     const auto kappa_max = static_cast<Float>(p.kappa_max);
     const auto alpha = static_cast<Float>(p.alpha);
     const auto theta = static_cast<Float>(p.theta);
-    const auto delta = p.delta < 0 ? norm_costs.min_abs() - theta * norm_costs.min_abs()
-                                   : static_cast<Float>(p.delta);
+    auto delta_for = [&](const cost_type<Float>& c) {
+        return p.delta < 0 ? c.min_abs() - theta * c.min_abs() : static_cast<Float>(p.delta);
+    };
+    const auto delta = delta_for(norm_costs);
     const auto pushing_k_factor = static_cast<Float>(p.pushing_k_factor);
     const auto pushing_objective_amplifier = static_cast<Float>(p.pushing_objective_amplifier);
     const long w_limit = static_cast<long>(p.w);
@@ -1448,8 +1456,11 @@ optimize_problem(const context& ctx, const problem& pb)
 
     lap("merged constraints, recorder");
     tm.host_setup = since_begin();
-    device_pool slv(ctx, constraints, variables, norm_costs, device_kind(pb.problem_type),
+    device_pool slv(ctx, constraints, variables, norm_costs_w, device_kind(pb.problem_type),
                     maximize, workers);
+    if (own_costs)
+        for (const auto& c : norm_costs_w)
+            slv.delta_of.push_back(static_cast<double>(delta_for(c)));
 
     struct worker
     {

@@ -145,6 +145,48 @@ updated_cb(int remaining_constraints, double value, int loop, double duration, l
 }
 
 void
+started_cb(const bx::solver_parameters&) // :30-35 (flushes the R console)
+{
+    std::fflush(stdout);
+}
+
+void
+finished_cb(const bx::result& r) // :70-111
+{
+    switch (r.status) {
+    case bx::result_status::success:
+        if (r.loop >= 0)
+            std::printf("Best solution found: %f in %ld loop and %fs\n", r.solutions.back().value, r.loop,
+                        r.duration);
+        else
+            std::printf("Best solution found via push: %f in %ld loop and %fs\n", r.solutions.back().value,
+                        -r.loop, r.duration);
+        break;
+    case bx::result_status::internal_error:
+        std::printf("No solution. Internal error\n");
+        break;
+    case bx::result_status::uninitialized:
+        std::printf("No solution. Uninitialized error\n");
+        break;
+    case bx::result_status::kappa_max_reached:
+        std::printf("No solution. Constraint remaining: %d. Kappa reached in %fs.\n", r.remaining_constraints,
+                    r.duration);
+        break;
+    case bx::result_status::time_limit_reached:
+        std::printf("No solution. Constraint remaining: %d. Time limit reached at %fs.\n",
+                    r.remaining_constraints, r.duration);
+        break;
+    case bx::result_status::limit_reached:
+        std::printf("No solution. Constraint remaining: %d. Loop limit reached in %fs.\n",
+                    r.remaining_constraints, r.duration);
+        break;
+    default:
+        break;
+    }
+    std::fflush(stdout);
+}
+
+void
 convert_result(const bx::result& res, bool minimize, bxr_result* out) // :241-289
 {
     std::memset(out, 0, sizeof *out);
@@ -188,8 +230,8 @@ run_glue(const char* file_path, int verbose, bxr_result* out, Fill fill, Run run
     bool minimize = true;
     try {
         auto ctx = bx::make_context(verbose ? 6 : 4);
-        if (verbose)
-            bx::context_register(ctx, bx::solver_started_cb(), updated_cb, bx::solver_finished_cb());
+        // all three callbacks whatever `verbose` is (:398-401, :556-559): it only sets the log level
+        bx::context_register(ctx, started_cb, updated_cb, finished_cb);
         auto pb = bx::make_problem(ctx, file_path ? file_path : "");
         minimize = (pb.type == bx::objective_function_type::minimize);
         sp params;

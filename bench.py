@@ -577,9 +577,10 @@ def main():
     dev.kernel_time(reset=True)
     st0 = dev.status()
     # the exchange step of the restart pool: every T steps the ranks
-    # agree on the incumbent -- allreduce(min) of the objective, broadcast of the
-    # winner's x (baryonyx_amd/dist.py) -- inside the timed region
-    incumbent = {"value": np.inf, "x": None, "exchanges": 0}
+    # agree on the incumbent -- ONE allreduce(min) of the packed key (violated rows,
+    # objective, rank), then the winner's x in one masked allreduce, no host sync
+    # between the two (baryonyx_amd/dist.py) -- inside the timed region
+    incumbent = {"value": np.inf, "x": None, "exchanges": 0, "remaining": None}
 
     def local_best():
         st = dev.status()
@@ -594,11 +595,16 @@ def main():
     def exchange():
         from baryonyx_amd.dist import reduce_incumbent
         best, best_b = local_best()
+        remaining = 0
         if incumbent["x"] is not None and incumbent["value"] <= best:
             best, xw = incumbent["value"], incumbent["x"]
-        else:
-            xw = dev.get_x(best_b) if best_b >= 0 else np.zeros(dev.nwords, np.uint64)
-        val, xall, _ = reduce_incumbent(best, xw, device="cpu" if share else "cuda")
+        elif best_b >= 0:
+            xw = dev.get_x(best_b)
+        else:  # nothing feasible yet: offer the restart with the fewest violated rows
+            rem = np.asarray(dev.status()["remaining"])
+            worst_b = int(rem.argmin())
+            remaining, xw = int(rem[worst_b]), dev.get_x(worst_b)
+        val, xall, _ = reduce_incumbent(best, xw, device="cpu" if share else "cuda", remaining=remaining)
         incumbent["value"], incumbent["x"] = val, xall
         incumbent["exchanges"] += 1
 

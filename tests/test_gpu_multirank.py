@@ -43,3 +43,23 @@ def test_two_ranks_share_the_gpu():
     # the incumbent went round (allreduce(min) + broadcast of the winner's x) every
     # second step inside the timed region and once at the end
     assert rec["config"]["incumbent_exchanges"] == 4 and rec["config"]["world_size"] == 2
+
+
+def test_two_ranks_on_the_telebus_shape():
+    """BASELINE configs[4] (inequalities-Z, 256 restarts per GPU) over two ranks on
+    the one GPU of the box: restarts sharded, the packed-key exchange inside the timed
+    region."""
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c5", "--batch", "256", "--steps", "4",
+           "--warmup", "1", "--cpu-seconds", "0", "--exchange-every", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 4
+    assert rec["config"]["restarts_per_gpu"] == 256 and rec["config"]["world_size"] == 2
+    assert rec["config"]["row_updates"] > 0 and rec["value"] > 0
+    assert rec["config"]["incumbent_exchanges"] == 3

@@ -54,6 +54,14 @@ OPT_CASES = [
     ("crossover-no-mutation-f32", lambda: synth.make_pm1(50, 250, 0.06, "real", 43), 0, 5, 250,
      dict(limit=20, w=5.0, init_population_size=10, init_kappa_improve_stop=0.04,
           init_mutation_value_mean=0.0, init_mutation_value_stddev=0.0)),
+    # cost_norm = random: every worker normalises with its OWN engine and so solves with its
+    # own cost vector and its own automatic delta (itm-optimizer-common.hpp:633-638,
+    # make_random_norm itm-common.hpp:1025-1075) -- one handle per worker on the device side
+    ("random-norm-per-worker", lambda: synth.make_scp(60, 400, 0.06, "int", 51), 1, 6, 250,
+     dict(limit=60, w=5.0, init_population_size=12, cost_norm=1)),
+    ("random-norm-per-worker-pm1-f32", lambda: synth.make_pm1(50, 250, 0.06, "int", 52), 0, 4, 200,
+     dict(limit=50, w=5.0, init_population_size=10, cost_norm=1, delta=0.01, pushes_limit=3,
+          pushing_iteration_limit=6)),
 ]
 
 
@@ -155,14 +163,18 @@ def test_optimize_over_several_devices_is_the_same_run(oracle, tmp_path, monkeyp
     assert np.array_equal(tr3["pop_hash"], otr["pop_hash"]) and np.array_equal(tr3["worker_rng"], otr["worker_rng"])
 
 
-def test_optimize_refuses_the_random_cost_norm(tmp_path):
-    """Every worker of the reference's optimize draws its OWN random-norm cost
-    vector (itm-optimizer-common.hpp:633-638); the batch shares one, so optimize
-    with more than one worker says so instead of running something else."""
+def test_random_cost_norm_gives_every_worker_its_own_costs(oracle, tmp_path):
+    """With integer costs (many equal ones) make_random_norm spreads the equal
+    costs with draws from the worker's engine: two workers do not hold the same
+    vector, and the run differs from one that would share worker 0's."""
     path = str(tmp_path / "p.lp")
     synth.write_lp(synth.make_scp(40, 200, 0.08, "int", 5), path)
-    with pytest.raises(RuntimeError, match="solver_failure"):
-        H.run(path, 1, H.default_params(seed=3, thread=4, cost_norm=1, sweep_budget=10, time_limit=5.0))
-    res, _ = H.run(path, 1, H.default_params(seed=3, thread=1, cost_norm=1, sweep_budget=50, time_limit=5.0))
-    assert res.status in (0, 3)
-
+    inst = H.merged(path)
+    hp, okw = both_params(oracle, seed=3, thread=4, cost_norm=1, sweep_budget=120, time_limit=600.0, limit=40,
+                          w=5.0, init_population_size=10)
+    res, tr = H.optimize_trace(path, hp, inst.n)
+    ores, otr = oracle.optimize(inst, 1, oracle.default_params(sort_mode=1, **okw), thread=4, rounds=120)
+    for k in ("worker_calls", "worker_rng", "pop_remaining", "pop_value", "pop_hash", "pop_x"):
+        assert np.array_equal(tr[k], otr[k]), k
+    res1, _ = H.run(path, 1, H.default_params(seed=3, thread=1, cost_norm=1, sweep_budget=50, time_limit=5.0))
+    assert res1.status in (0, 3)
