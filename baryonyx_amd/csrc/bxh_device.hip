@@ -117,8 +117,10 @@ set_lds_limits(int device)
     BXH_SET_LDS(bxh::sweep_kernel<float, true>);
     BXH_SET_LDS(bxh::sweep_kernel<double, false>);
     BXH_SET_LDS(bxh::sweep_kernel<double, true>);
-    BXH_SET_LDS(bxh::sweep_kernel_z<float>);
-    BXH_SET_LDS(bxh::sweep_kernel_z<double>);
+    BXH_SET_LDS(bxh::sweep_kernel_z<float, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_z<double, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_z<float, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_z<double, true>);
     BXH_SET_LDS(bxh::order_post_kernel<float>);
     BXH_SET_LDS(bxh::order_post_kernel<double>);
     BXH_SET_LDS(bxh::order_init_kernel<float>);
@@ -290,6 +292,8 @@ struct bxh_handle_s
     DevBuf<unsigned> lcg_pow;           // 16807^k mod 2^31-1
     DevBuf<unsigned char> q_factor;
     DevBuf<signed char> zkind;
+    DevBuf<unsigned long long> zconf; // Z kernel: rows k + 1 .. k + 64 that share a column with row k
+    int zwave = 0;                    // Z kernel: rows of up to 63 elements go wave per row (groups)
     DevBuf<unsigned char> zscratch;
     DevBuf<int> mcount, mrun, slist, vamt, sid;
     DevBuf<unsigned long long> skey;
@@ -481,7 +485,10 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
         }
 #undef BXH_V2
     } else if (h->version == 3) {
-        BXH_LAUNCH((bxh::sweep_kernel_z<Float>));
+        if (h->zwave)
+            BXH_LAUNCH((bxh::sweep_kernel_z<Float, true>));
+        else
+            BXH_LAUNCH((bxh::sweep_kernel_z<Float, false>));
     } else if (h->version == 5) {
 #define BXH_NARROW(PM, WW, RQ)                                                 \
     hipLaunchKernelGGL((bxh::sweep_kernel_narrow<Float, PM, WW, RQ>), dim3(h->batch), dim3(64 * WW), \
@@ -649,7 +656,7 @@ bxh_create(const bxh_problem* pb,
             if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
                 cus = prop.multiProcessorCount;
             // every workgroup should get a tile (32 columns) per wave of the longest row
-            wide_g = std::max(1, std::min(cus / batch, rmax / 256));
+            wide_g = std::max(1, std::min({ cus / batch, rmax / 256, 64 }));
             if (asked && std::atoi(eg + 1) > 0)
                 wide_g = std::atoi(eg + 1);
             if (batch * wide_g > cus || wide_g > 64)
@@ -1048,12 +1055,22 @@ bxh_create(const bxh_problem* pb,
                 ex_count[k] = nb;
             }
         }
-        const int zl = bxh::lds_bytes_z(m, h->nwords, rmax, static_cast<int>(h->fsize));
+        // wave-per-row groups (bxh_kernels.hpp: sweep_kernel_z<Float, true>): linear objective
+        {
+            const char* ez = std::getenv("BXH_ZWAVE");
+            h->zwave = (pb->n_quad == 0 && !(ez && ez[0] == '0')) ? 1 : 0;
+            if (h->zwave &&
+                bxh::lds_bytes_z(m, h->nwords, rmax, static_cast<int>(h->fsize), true) > lds_limit)
+                h->zwave = 0;
+        }
+        const int zl = bxh::lds_bytes_z(m, h->nwords, rmax, static_cast<int>(h->fsize), h->zwave != 0);
         if (zl > lds_limit)
             return fail(BXH_ERR_UNSUPPORTED, "instance does not fit the Z kernel's LDS plan");
         h->version = 3;
         h->lds_bytes = static_cast<size_t>(zl);
         h->threads = std::min(h->threads, 256); // sweep_kernel_z's launch bound (longer rows loop)
+        if (h->zwave)
+            h->threads = 256; // four waves: up to four rows side by side
     }
     if (v2_ok) {
         const int np = cmax <= 64 ? 4 : (cmax <= 80 ? 5 : (cmax <= 96 ? 6 : 8));
@@ -1176,6 +1193,28 @@ bxh_create(const bxh_problem* pb,
         HIP_TRY(h->fac32.upload(fac32));
         HIP_TRY(h->col_fac.upload(col_fac));
         HIP_TRY(h->zkind.upload(zkind));
+        {
+            // bit d - 1 of zconf[k]: row k + d holds a column of row k (d = 1 .. 64).  Rows
+            // that share no column commute exactly (neither reads what the other writes), so
+            // the kernel runs such neighbours of the row list side by side, a wave each.
+            std::vector<unsigned long long> conf(static_cast<size_t>(m), 0ull);
+            std::vector<std::vector<int>> recent(static_cast<size_t>(n));
+            for (int k = 0; k != m; ++k)
+                for (int e = pb->row_ptr[k]; e != pb->row_ptr[k + 1]; ++e) {
+                    auto& rj = recent[static_cast<size_t>(pb->col[e])];
+                    size_t keep = 0;
+                    for (size_t t = 0; t != rj.size(); ++t)
+                        if (k - rj[t] <= 64) {
+                            if (rj[t] != k)
+                                conf[static_cast<size_t>(rj[t])] |= 1ull << (k - rj[t] - 1);
+                            rj[keep++] = rj[t];
+                        }
+                    rj.resize(keep);
+                    if (rj.empty() || rj.back() != k)
+                        rj.push_back(k);
+                }
+            HIP_TRY(h->zconf.upload(conf));
+        }
         HIP_TRY(h->ex_start.upload(ex_start));
         HIP_TRY(h->ex_count.upload(ex_count));
         HIP_TRY(h->ex_flat.upload(ex_flat));
@@ -1491,6 +1530,8 @@ bxh_create(const bxh_problem* pb,
     dp.ex_start = h->ex_start.p;
     dp.ex_count = h->ex_count.p;
     dp.ex_flat = h->ex_flat.p;
+    dp.zconf = h->zconf.p;
+    dp.zwave = h->zwave;
     dp.bmin = h->bmin.p;
     dp.bmax = h->bmax.p;
     dp.bneg = h->bneg.p;
@@ -1718,7 +1759,7 @@ bxh_create_device(const bxh_problem* pb,
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
     }
-    int wide_g = std::max(1, std::min(cus / batch, rmax / 256));
+    int wide_g = std::max(1, std::min({ cus / batch, rmax / 256, 64 })); // (a small batch: at most 64 per instance)
     if (const char* eg = std::getenv("BXH_GROUPS"))
         if (eg[0] == 'w' && std::atoi(eg + 1) > 0)
             wide_g = std::atoi(eg + 1);
@@ -1915,7 +1956,7 @@ bxh_kernel_form(bxh_handle h)
     if (!h)
         return BXH_ERR_INVALID;
     if (h->version == 3)
-        return 3;
+        return h->zwave ? 6 : 3;
     if (h->version == 4)
         return 100 + h->wide_g;
     if (h->version == 5)

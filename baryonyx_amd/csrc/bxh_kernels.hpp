@@ -72,6 +72,8 @@ struct DevProblem
     const int* ex_start;       // [m]     first pattern of row k in ex_flat (exhaustive rows)
     const int* ex_count;       // [m]     number of patterns
     const int* ex_flat;        //         patterns: factor or 0 per element, row after row
+    const unsigned long long* zconf; // [m] bit d - 1: row k + d shares a column with row k (d = 1 .. 64)
+    int zwave;                 // 1: sweep_kernel_z<Float, true> (rows of up to 63 elements: a wave per row)
     const int* bmin;           // [m] clamped as the Solver constructor does
     const int* bmax;           // [m]
     const int* bneg;           // [m] negative_factor (== c_size of the row)
@@ -1761,8 +1763,25 @@ constexpr int Z_LDS_LIMIT = 160 * 1024; // the LDS of a gfx950 CU (bxh_device.hi
 
 // LDS of the Z kernel: the plan of the lane-per-column kernel, then the
 // factor of every R position and a 0/1 result per position.
+// The wave-per-row form (sweep_kernel_z<Float, true>): every wave has its own set
+// of row buffers (64 entries each: values by element, values / keys / element ids /
+// factors by position, positions by element, sub-solver results) and the workgroup
+// a table of the next ZW_TABLE rows of the list (scalars + conflict masks).
+constexpr int ZW_WAVES = 4;  // waves of the Z kernel's workgroup (256 threads)
+constexpr int ZW_TABLE = 64; // rows of the list staged in LDS at a time (== a wave: the group scan uses ballots)
+__host__ __device__ constexpr int
+zw_wave_bytes(int fsize)
+{
+    return 64 * (2 * fsize + 8 + 4 * 4);
+}
+__host__ __device__ constexpr int
+zw_table_bytes()
+{
+    return ZW_TABLE * (8 * 4 + 8 + 8);
+}
+
 __host__ __device__ inline int
-lds_bytes_z_base(int m, int nwords, int rmax, int fsize)
+lds_bytes_z_base(int m, int nwords, int rmax, int fsize, bool zw)
 {
     const LdsPlan lp = lds_plan(m, nwords, rmax, fsize);
     const int n2 = next_pow2(rmax < 64 ? 64 : rmax); // whole 64-entry runs
@@ -1770,24 +1789,26 @@ lds_bytes_z_base(int m, int nwords, int rmax, int fsize)
     // run_merge_sort, + the row's descriptors {first slot, padded length,
     // own slot, column} by row-local id
     return lp.total + 2 * (((rmax + 1) * 4 + 15) & ~15) + ((n2 * 8 + 15) & ~15) +
-           ((n2 * 4 + 15) & ~15) + ((rmax * 16 + 15) & ~15);
+           ((n2 * 4 + 15) & ~15) + ((rmax * 16 + 15) & ~15) +
+           (zw ? ZW_WAVES * zw_wave_bytes(fsize) + zw_table_bytes() : 0);
 }
 
 // The node stack sits in LDS only when it is small AND the plan still fits with
 // it; otherwise the kernel uses the per-instance global scratch (host and kernel
 // decide with this one function).
 __host__ __device__ inline bool
-z_stack_in_lds(int m, int nwords, int rmax, int fsize)
+z_stack_in_lds(int m, int nwords, int rmax, int fsize, bool zw)
 {
     const int zs = (int)((zscratch_size(rmax, fsize) + 15) & ~(size_t)15);
-    return zs <= Z_SCRATCH_LDS && lds_bytes_z_base(m, nwords, rmax, fsize) + zs <= Z_LDS_LIMIT;
+    return zs <= Z_SCRATCH_LDS && lds_bytes_z_base(m, nwords, rmax, fsize, zw) + zs <= Z_LDS_LIMIT;
 }
 
 __host__ __device__ inline int
-lds_bytes_z(int m, int nwords, int rmax, int fsize)
+lds_bytes_z(int m, int nwords, int rmax, int fsize, bool zw)
 {
     const int zs = (int)((zscratch_size(rmax, fsize) + 15) & ~(size_t)15);
-    return lds_bytes_z_base(m, nwords, rmax, fsize) + (z_stack_in_lds(m, nwords, rmax, fsize) ? zs : 0);
+    return lds_bytes_z_base(m, nwords, rmax, fsize, zw) +
+           (z_stack_in_lds(m, nwords, rmax, fsize, zw) ? zs : 0);
 }
 
 // One thread: the depth-first search of branch_and_bound_solver::solve
@@ -1924,7 +1945,16 @@ bb_search(const Float* val_s,
 // One sweep of one instance of the Z solver: compute_order::run /
 // push_and_run around compute_update_row / push_and_compute_update_row of
 // itm-solver-inequalities-Z.cpp:441-564 (one workgroup per instance).
-template<typename Float>
+//
+// ZW = true (linear objective): rows of up to 63 elements are worked on by ONE WAVE
+// each, wave-synchronously (no workgroup barrier inside a row), and up to four
+// consecutive rows of the list that share no column -- they commute exactly: neither
+// reads pi, P or x entries the other writes -- run side by side, a wave each, between
+// two barriers.  What the reference does in sequence stays in sequence: the tie
+// shuffles draw from the engine in row order (thread 0, behind the first barrier),
+// and R's leftovers (`stale`) are written in row order.  Longer rows and the
+// constrained sub-solver kinds take the general path below, alone.
+template<typename Float, bool ZW>
 __global__ __launch_bounds__(256) void // (256 threads at most: the cached column slots want registers)
 sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
 {
@@ -1964,9 +1994,23 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     int* out_list = keep ? st.slist + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
     const Float* cost = (const Float*)pb.cost;
     // (the node stack of the branch-and-bound rows: behind the descriptors in LDS when small)
-    unsigned char* scratch = z_stack_in_lds(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float))
-                               ? (unsigned char*)desc_s + ((pb.rmax * 16 + 15) & ~15)
+    unsigned char* const zw_base = (unsigned char*)desc_s + ((pb.rmax * 16 + 15) & ~15);
+    constexpr int ZWB = ZW ? ZW_WAVES * zw_wave_bytes((int)sizeof(Float)) + zw_table_bytes() : 0;
+    unsigned char* scratch = z_stack_in_lds(pb.m, pb.nwords, pb.rmax, (int)sizeof(Float), ZW)
+                               ? zw_base + ZWB
                                : st.zscratch + (size_t)inst * st.zscratch_bytes;
+    // ZW: the row table (next ZW_TABLE rows of the list) behind the waves' buffers
+    unsigned char* const zt_base = zw_base + ZW_WAVES * zw_wave_bytes((int)sizeof(Float));
+    unsigned long long* const t_conf = (unsigned long long*)zt_base;
+    double* const t_rb = (double*)(zt_base + ZW_TABLE * 8);
+    int* const t_k = (int*)(zt_base + ZW_TABLE * 16);
+    int* const t_rs = t_k + ZW_TABLE;
+    int* const t_re = t_rs + ZW_TABLE;
+    int* const t_z = t_re + ZW_TABLE;
+    int* const t_bmin = t_z + ZW_TABLE;
+    int* const t_bmax = t_bmin + ZW_TABLE;
+    int* const t_g = t_bmax + ZW_TABLE;  // rows of the group that starts at this slot (0: general path)
+    int* const t_cb = t_g + ZW_TABLE;    // bit u - 1: clashes with the row u slots back; bit 8: simple
     unsigned* const err_word = st.cnt + 2 * gridDim.x;
 
     const Float kappa = (Float)a.kappa[inst];
@@ -2028,6 +2072,97 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         return cost_x<Float>(pb, x_s, j, cost[j]) - acc;
     };
 
+    // The two sub-solvers (all threads; barriers inside): submode 1 = branch and
+    // bound, 2 = exhaustive, on a row whose values sit in val_s (by element), the
+    // sorted order in id_s / fz_s (by position); leaves R's new order in id_s and the
+    // split index in misc_s[MS_SEL].
+    auto subsolve = [&](const int submode, const int k, const int r, const int bkmin, const int bkmax,
+                        const Float* val_s, int* id_s, int* fz_s, int* res_s) {
+            if (submode == 1) {
+                if (tid == 0) {
+                    if (!bb_search<Float>(val_s, id_s, fz_s, r, bkmin, bkmax, maximize, scratch, res_s))
+                        __hip_atomic_store(err_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            } else if (submode == 2) {
+                // exhaustive_solver::solve, exhaustive-solver.hpp:185-252: the
+                // best of the row's precomputed feasible patterns, the first one
+                // among equals (one thread per pattern, sums in element order)
+                const int start = pb.ex_start[k], nsol = pb.ex_count[k];
+                if (tid == 0) {
+                    key_s[0] = ~0ull;
+                    misc_s[MS_CNT] = 0x7fffffff;
+                }
+                __syncthreads();
+                for (int t = tid; t < nsol; t += T) {
+                    Float z = 0;
+                    for (int jx = 0; jx < r; ++jx)
+                        if (pb.ex_flat[start + t * r + jx])
+                            z += val_s[id_s[jx]];
+                    atomicMin(&key_s[0], order_key<Float>(z, maximize));
+                }
+                __syncthreads();
+                for (int t = tid; t < nsol; t += T) {
+                    Float z = 0;
+                    for (int jx = 0; jx < r; ++jx)
+                        if (pb.ex_flat[start + t * r + jx])
+                            z += val_s[id_s[jx]];
+                    if (order_key<Float>(z, maximize) == key_s[0])
+                        atomicMin(&misc_s[MS_CNT], t);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    const int best = misc_s[MS_CNT];
+                    for (int i = 0; i < r; ++i)
+                        res_s[i] = pb.ex_flat[start + best * r + i] ? 1 : 0;
+                }
+                __syncthreads();
+            }
+            if (submode != 0) {
+                // both sub-solvers end with a sort by (result first, then value)
+                // and return the split index (:219-252, :505-533)
+                if (tid == 0) {
+                    int* tmp = (int*)key_s; // ids in the new order
+                    int cnt1 = 0;
+                    if (submode == 1) { // R is sorted by value: a stable partition
+                        for (int i = 0; i < r; ++i)
+                            if (res_s[i])
+                                tmp[cnt1++] = id_s[i];
+                        int z0 = cnt1;
+                        for (int i = 0; i < r; ++i)
+                            if (!res_s[i])
+                                tmp[z0++] = id_s[i];
+                    } else { // at most 9 items: libstdc++'s insertion sort
+                        for (int i = 0; i < r; ++i) {
+                            tmp[i] = id_s[i];
+                            tmp[r + i] = res_s[i];
+                            cnt1 += res_s[i];
+                        }
+                        auto less = [&](int ia, int ra, int ib, int rb) -> bool {
+                            if (ra == rb)
+                                return maximize ? val_s[ia] > val_s[ib] : val_s[ia] < val_s[ib];
+                            return ra > rb;
+                        };
+                        for (int i = 1; i < r; ++i) {
+                            const int vi = tmp[i], vr = tmp[r + i];
+                            int jx = i;
+                            while (jx > 0 && less(vi, vr, tmp[jx - 1], tmp[r + jx - 1])) {
+                                tmp[jx] = tmp[jx - 1];
+                                tmp[r + jx] = tmp[r + jx - 1];
+                                --jx;
+                            }
+                            tmp[jx] = vi;
+                            tmp[r + jx] = vr;
+                        }
+                    }
+                    for (int i = 0; i < r; ++i)
+                        id_s[i] = tmp[i];
+                    misc_s[MS_SEL] = cnt1 == r ? r : cnt1 - 1;
+                }
+                __syncthreads();
+            }
+    };
+
     // the next row's scalars travel while this row is worked on
     struct RowZ
     {
@@ -2049,18 +2184,509 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         return x;
     };
     RowZ nxt = { 0, 0, 0, 0, 0, 0, 0.0 };
-    if (nrows > 0)
+    if (!ZW && nrows > 0)
         nxt = row_of(row_id(0));
-    int k_ahead = nrows > 1 ? row_id(1) : 0; // the row after `nxt`
+    int k_ahead = (!ZW && nrows > 1) ? row_id(1) : 0; // the row after `nxt`
     bool pre_ok = false; // the lane's element descriptor of the next row is in registers
     int2 pre_cs = make_int2(0, 0);
     int pre_j = 0, pre_pe = 0, pre_f = 0;
+
+    // ---- ZW: the row table, the groups, the wave-per-row path ---------------------
+    const int wave = tid >> 6, lane = tid & 63, NW = T >> 6;
+    int* const zflag = misc_s + MS_WAVES + 40; // [0..3] tie, [4..7] sub-solver wanted, [8..11] sel
+    unsigned char* const zw_mine = zw_base + wave * zw_wave_bytes((int)sizeof(Float));
+    auto w_val = [&](int w) { return (Float*)(zw_base + w * zw_wave_bytes((int)sizeof(Float))); };      // by element
+    auto w_vs = [&](int w) { return w_val(w) + 64; };                                                  // by position
+    auto w_key = [&](int w) { return (unsigned long long*)(w_val(w) + 128); };                         // by position
+    auto w_idp = [&](int w) { return (int*)(w_key(w) + 64); };                                         // element by position
+    auto w_fzp = [&](int w) { return w_idp(w) + 64; };                                                 // factor by position
+    auto w_pos = [&](int w) { return w_idp(w) + 128; };                                                // position by element
+    auto w_res = [&](int w) { return w_idp(w) + 192; };
+    (void)zw_mine;
+    int tbase = -0x40000000; // list position of table slot 0
+    // inclusive prefix sum of an int over the wave (DPP: shifts inside a row of 16 lanes,
+    // then the row totals handed on by row_bcast:15 / row_bcast:31)
+    auto wave_scan = [&](int v) -> int {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); // row_shr:1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true); // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); // row_shr:4
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true); // row_shr:8
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+        return v;
+    };
+    // the lane's element descriptor of its row in the NEXT group, fetched a group ahead
+    double alg_w = 0.0; // algorithmic bytes of the rows this wave took
+    int zp_pos = -1;
+    int2 zp_cs = make_int2(0, 0);
+    int zp_j = 0, zp_pe = 0, zp_f = 0;
+    Float zp_cost = 0;
+
     for (int it = 0; it < nrows; ++it) {
-        const RowZ cur = nxt;
-        if (it + 1 < nrows)
-            nxt = row_of(k_ahead);
-        if (it + 2 < nrows)
-            k_ahead = row_id(it + 2);
+        RowZ cur = nxt;
+        if (ZW) {
+            if (it + 2 * NW > tbase + ZW_TABLE && (tbase < 0 || tbase + ZW_TABLE < nrows)) {
+                BXH_STAMP(7);
+                __syncthreads(); // (nobody reads the old table any more)
+                tbase = it;
+                if (tid < ZW_TABLE && it + tid < nrows) {
+                    const RowZ x = row_of(row_id(it + tid));
+                    t_k[tid] = x.k;
+                    t_rs[tid] = x.rs;
+                    t_re[tid] = x.re;
+                    t_z[tid] = x.zk;
+                    t_bmin[tid] = x.bmin;
+                    t_bmax[tid] = x.bmax;
+                    t_rb[tid] = x.rbytes;
+                    t_conf[tid] = pb.zconf[x.k];
+                }
+                __syncthreads();
+                // which of the three rows in front does a row clash with (shares a column,
+                // or too far apart in the matrix for the masks to tell), and is it a row a
+                // wave can take: at most 63 elements, a kind whose selection is the scan
+                if (tid < ZW_TABLE) {
+                    int cb = 0;
+                    if (it + tid < nrows) {
+                        const int rr = t_re[tid] - t_rs[tid];
+                        if (rr >= 1 && rr <= 63 && t_z[tid] >= Z_UNCONSTRAINED_BB)
+                            cb = 0x100;
+                        const int k2 = t_k[tid];
+                        for (int u = 1; u <= 3 && u <= tid; ++u) {
+                            const int k1 = t_k[tid - u];
+                            const int lo = k1 < k2 ? tid - u : tid;
+                            const int d = k1 < k2 ? k2 - k1 : k1 - k2;
+                            if (d == 0 || d > 64 || ((t_conf[lo] >> (d - 1)) & 1ull))
+                                cb |= 1 << (u - 1);
+                        }
+                    }
+                    // the groups: consecutive simple rows, pairwise without a clash (wave 0
+                    // has the 64 rows' bits in four ballots; lane 0 walks them)
+                    const unsigned long long smask = __ballot((cb & 0x100) != 0);
+                    const unsigned long long c1 = __ballot((cb & 1) != 0), c2 = __ballot((cb & 2) != 0),
+                                             c3 = __ballot((cb & 4) != 0);
+                    // (every lane works out the group that WOULD start at its slot; the loop only
+                    // ever asks at slots where one does)
+                    int gs = 0;
+                    if ((smask >> tid) & 1ull) {
+                        gs = 1;
+                        while (gs < NW && tid + gs < ZW_TABLE && ((smask >> (tid + gs)) & 1ull)) {
+                            const int at = tid + gs;
+                            const int cbits = (int)((c1 >> at) & 1ull) | ((int)((c2 >> at) & 1ull) << 1) |
+                                              ((int)((c3 >> at) & 1ull) << 2);
+                            if (cbits & ((1 << gs) - 1))
+                                break;
+                            ++gs;
+                        }
+                    }
+                    t_g[tid] = gs;
+                }
+                __syncthreads();
+            }
+            const int g = __builtin_amdgcn_readfirstlane(t_g[it - tbase]);
+            if (g > 0) {
+                BXH_STAMP(8);
+                const int s0 = it - tbase;
+                const bool mine = wave < g;
+                const int sl = s0 + (mine ? wave : 0);
+                const int k = __builtin_amdgcn_readfirstlane(t_k[sl]);
+                const int rs = __builtin_amdgcn_readfirstlane(t_rs[sl]);
+                const int r = mine ? __builtin_amdgcn_readfirstlane(t_re[sl]) - rs : 0;
+                const int zk = __builtin_amdgcn_readfirstlane(t_z[sl]);
+                const int bkmin = __builtin_amdgcn_readfirstlane(t_bmin[sl]);
+                const int bkmax = __builtin_amdgcn_readfirstlane(t_bmax[sl]);
+                Float* const val_w = w_val(wave);
+                Float* const vs_w = w_vs(wave);
+                unsigned long long* const key_w = w_key(wave);
+                int* const idp_w = w_idp(wave);
+                int* const fzp_w = w_fzp(wave);
+                int* const pos_w = w_pos(wave);
+
+                // ---- phase A: the lane's column -> reduced cost -> rank ----------------
+                // The first 16 slots of the lane's column stay in registers for the whole row:
+                // P, |a| and -- the rows of a group share no column, so nothing a partner
+                // writes is in this column -- the pi of the slots' rows, read from LDS ONCE;
+                // the repair pass only swaps in the row's own slot (new pi_k, new P).
+                Float c_p[16], c_f[16], c_pi[16];
+                int c_r[16];
+                int4 c_desc = make_int4(0, 0, 0, 0);
+                Float c_cost = 0;
+                int fe = 0;
+                if (lane < r) {
+                    int2 cs;
+                    int j, pe;
+                    if (zp_pos == it + wave) { // fetched while the previous group was worked on
+                        cs = zp_cs;
+                        j = zp_j;
+                        pe = zp_pe;
+                        fe = zp_f;
+                        c_cost = zp_cost;
+                    } else {
+                        const int e = rs + lane;
+                        cs = pb.row_cs[e];
+                        j = pb.row_col[e];
+                        pe = pb.row_pos[e];
+                        fe = pb.fac32[e];
+                        c_cost = cost[j];
+                    }
+                    c_desc = make_int4(cs.x, cs.y & 0xffff, pe, j);
+                    // (columns are padded to 16 slots: 16-byte loads, all in flight together)
+                    if (sizeof(Float) == 8) {
+                        const double2* pv = reinterpret_cast<const double2*>((const double*)P + cs.x);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const double2 t2 = pv[u];
+                            c_p[2 * u] = (Float)t2.x;
+                            c_p[2 * u + 1] = (Float)t2.y;
+                        }
+                    } else {
+                        const float4* pv = reinterpret_cast<const float4*>((const float*)P + cs.x);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 t4 = pv[u];
+                            c_p[4 * u] = (Float)t4.x;
+                            c_p[4 * u + 1] = (Float)t4.y;
+                            c_p[4 * u + 2] = (Float)t4.z;
+                            c_p[4 * u + 3] = (Float)t4.w;
+                        }
+                    }
+                    const int4* fv = reinterpret_cast<const int4*>(pb.col_fac + cs.x);
+                    const int4* rv = reinterpret_cast<const int4*>(pb.col_row + cs.x);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int4 f4 = fv[u], r4 = rv[u];
+                        c_f[4 * u] = (Float)f4.x;
+                        c_f[4 * u + 1] = (Float)f4.y;
+                        c_f[4 * u + 2] = (Float)f4.z;
+                        c_f[4 * u + 3] = (Float)f4.w;
+                        c_r[4 * u] = r4.x;
+                        c_r[4 * u + 1] = r4.y;
+                        c_r[4 * u + 2] = r4.z;
+                        c_r[4 * u + 3] = r4.w;
+                    }
+                }
+                // the next group's descriptors: on their way while this one is worked on
+                {
+                    const int pos2 = it + g;
+                    zp_pos = -1;
+                    if (pos2 < nrows && pos2 + NW <= tbase + ZW_TABLE) {
+                        const int g2 = __builtin_amdgcn_readfirstlane(t_g[pos2 - tbase]);
+                        if (wave < g2) {
+                            const int sl2 = pos2 - tbase + wave;
+                            const int e2 = t_rs[sl2] + lane;
+                            zp_pos = pos2 + wave;
+                            if (e2 < t_re[sl2]) {
+                                zp_cs = pb.row_cs[e2];
+                                zp_j = pb.row_col[e2];
+                                zp_pe = pb.row_pos[e2];
+                                zp_f = pb.fac32[e2];
+                                zp_cost = cost[zp_j];
+                            }
+                        }
+                    }
+                }
+                // sum over the lane's column as the cached arrays stand (set_own puts the row's own
+                // entry -- pi_k and the not yet stored P -- into its slot first): the cached slots,
+                // then (columns of more than 16 entries) the rest
+                auto set_own = [&](Float pown, Float pik) {
+                    const int off = c_desc.z - c_desc.x;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        c_p[u] = u == off ? pown : c_p[u];
+                        c_pi[u] = u == off ? pik : c_pi[u];
+                    }
+                };
+                auto z_rc = [&](Float pown, Float pik) -> Float {
+                    Float acc = 0;
+                    const int q0 = c_desc.x, pe = c_desc.z;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        acc += c_f[u] * (c_pi[u] + c_p[u]);
+                    for (int qb = q0 + 16; qb < q0 + c_desc.y; qb += 8) {
+                        Float p8[8], pi8[8];
+                        int f8[8], r8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            p8[u] = P[qb + u];
+                            f8[u] = pb.col_fac[qb + u];
+                            r8[u] = pb.col_row[qb + u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            pi8[u] = pi_s[r8[u] < pb.m ? r8[u] : 0];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool own = qb + u == pe;
+                            acc += (Float)f8[u] * ((own ? pik : pi8[u]) + (own ? pown : p8[u]));
+                        }
+                    }
+                    return c_cost - acc;
+                };
+                auto z_own = [&]() -> Float { // P[pe] as it stands in memory
+                    const int off = c_desc.z - c_desc.x;
+                    Float v = 0;
+                    if (off < 16) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            v = u == off ? c_p[u] : v;
+                    } else
+                        v = P[c_desc.z];
+                    return v;
+                };
+                Float val = 0;
+                unsigned long long key = ~0ull;
+                int rank = 0;
+                bool tie = false;
+                int sel = -2;
+                // select_variables (:308-344) on ballots: lane t stands for i = t - 1.  (R[r],
+                // the leftover of an earlier row, is read by the reference at i = r - 1, where it
+                // cannot change `best` any more: left out.)
+                auto wave_select = [&]() -> int {
+                    const int i = lane - 1; // -1 .. 62
+                    const bool in = i < r;
+                    const int S = wave_scan((i >= 0 && i < r) ? fzp_w[i] : 0); // S_i (S_-1 = 0)
+                    const Float nv = i + 1 < r ? vs_w[i + 1] : (Float)0;
+                    const unsigned long long valid = __ballot(in && bkmin <= S && S <= bkmax);
+                    const unsigned long long stops = __ballot(in && i + 1 < r && (maximize ? nv < 0 : nv > 0));
+                    if (!valid)
+                        return -2;
+                    const int fv = __ffsll((long long)valid) - 1; // lane of the first valid i
+                    const unsigned long long after = stops & ~((1ull << fv) - 1ull);
+                    const int leave = after ? __ffsll((long long)after) - 1 : r; // lane; r == i = r - 1
+                    const unsigned long long upto = valid & (leave >= 63 ? ~0ull : ((2ull << leave) - 1ull));
+                    return (63 - __clzll((long long)upto)) - 1; // lane -> i
+                };
+                auto sub_wanted = [&](int sl_) -> int { // the unconstrained kinds, when the scan found nothing
+                    return (sl_ == -2 && zk == Z_UNCONSTRAINED_BB)
+                             ? 1
+                             : ((sl_ == -2 && zk == Z_UNCONSTRAINED_EXHAUSTIVE) ? 2 : 0);
+                };
+                BXH_STAMP(9);
+                Float pik_old = 0, p_decayed = 0;
+                if (mine) {
+                    if (lane < r) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) // (padding: any finite pi; its factor is 0)
+                            c_pi[u] = pi_s[c_r[u] < pb.m ? c_r[u] : 0];
+                        pik_old = pi_s[k];
+                        p_decayed = z_own() * theta; // decrease_preference (stored with affect's value)
+                        set_own(p_decayed, pik_old);
+                        val = z_rc(p_decayed, pik_old);
+                        if (push) // :467-469: the true column
+                            val += obj_amp * c_cost;
+                        key = order_key<Float>(val, maximize);
+                    }
+                    BXH_STAMP(10);
+                    // calculator_sort: the element's position = the number of keys below its own
+                    // (keys by element in LDS, read by broadcast, eight per round trip; the
+                    // padding up to a multiple of eight holds the largest key).  Two equal keys
+                    // land on one position, which the loser of the two stores sees: the row then
+                    // counts again with the ids (the canonical tie rule) and flags the tie.
+                    key_w[lane] = key; // (by element for now; lanes >= r: ~0)
+                    __builtin_amdgcn_wave_barrier();
+                    const int r8 = (r + 7) & ~7;
+                    for (int j0 = 0; j0 < r8; j0 += 8) {
+                        ulonglong2 q[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            q[u] = reinterpret_cast<const ulonglong2*>(key_w + j0)[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            rank += q[u].x < key;
+                            rank += q[u].y < key;
+                        }
+                    }
+                    if (lane < r)
+                        idp_w[rank] = lane;
+                    __builtin_amdgcn_wave_barrier();
+                    const bool lost = lane < r && idp_w[rank] != lane;
+                    tie = __ballot(lost) != 0ull;
+                    if (tie) {
+                        rank = 0;
+                        for (int j0 = 0; j0 < r8; j0 += 8) {
+                            ulonglong2 q[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                q[u] = reinterpret_cast<const ulonglong2*>(key_w + j0)[u];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                rank += (q[u].x < key) || (q[u].x == key && j0 + 2 * u < lane);
+                                rank += (q[u].y < key) || (q[u].y == key && j0 + 2 * u + 1 < lane);
+                            }
+                        }
+                        if (lane < r)
+                            idp_w[rank] = lane;
+                    }
+                    __builtin_amdgcn_wave_barrier(); // (every lane has read the keys by element)
+                    if (lane < r) {
+                        val_w[lane] = val;
+                        vs_w[rank] = val;
+                        fzp_w[rank] = fe;
+                    }
+                    if (tie) {
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < r)
+                            key_w[rank] = key; // by position: the runs the shuffle goes over
+                    } else {
+                        __builtin_amdgcn_wave_barrier();
+                        sel = wave_select();
+                    }
+                    if (lane == 0) {
+                        zflag[wave] = tie ? 1 : 0;
+                        zflag[4 + wave] = tie ? 0 : sub_wanted(sel);
+                        zflag[8 + wave] = sel;
+                    }
+                }
+                BXH_STAMP(11);
+                __syncthreads(); // B1: every row of the group is sorted
+                BXH_STAMP(12);
+
+                // ---- the tie shuffles, in row order, from the one engine -----------------
+                bool any_tie = false;
+                for (int w = 0; w < g; ++w)
+                    any_tie = any_tie || zflag[w] != 0;
+                if (any_tie) {
+                    if (tid == 0)
+                        for (int w = 0; w < g; ++w)
+                            if (zflag[w]) {
+                                const int rw = t_re[s0 + w] - t_rs[s0 + w];
+                                const unsigned long long* kw = w_key(w);
+                                int* iw = w_idp(w);
+                                int b0 = 0;
+                                for (int i = 1; i <= rw; ++i)
+                                    if (i == rw || kw[i] != kw[b0]) {
+                                        rng.shuffle(iw + b0, (unsigned)(i - b0));
+                                        b0 = i;
+                                    }
+                            }
+                    __syncthreads();
+                    if (mine && tie) { // the new positions (values of a run are equal: vs stays)
+                        if (lane < r)
+                            pos_w[idp_w[lane]] = lane;
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < r) {
+                            rank = pos_w[lane];
+                            fzp_w[rank] = fe;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        sel = wave_select();
+                        if (lane == 0) {
+                            zflag[4 + wave] = sub_wanted(sel);
+                            zflag[8 + wave] = sel;
+                        }
+                    }
+                    __syncthreads();
+                }
+                bool any_sub = false;
+                for (int w = 0; w < g; ++w)
+                    any_sub = any_sub || zflag[4 + w] != 0;
+                if (any_sub) {
+                    for (int w = 0; w < g; ++w)
+                        if (zflag[4 + w]) {
+                            const int slw = s0 + w;
+                            subsolve(zflag[4 + w], t_k[slw], t_re[slw] - t_rs[slw], t_bmin[slw], t_bmax[slw],
+                                     w_val(w), w_idp(w), w_fzp(w), w_res(w));
+                            if (tid == 0)
+                                zflag[8 + w] = misc_s[MS_SEL];
+                            __syncthreads();
+                        }
+                    if (mine && zflag[4 + wave]) { // R's new order: positions, values, factors
+                        sel = zflag[8 + wave];
+                        if (lane < r)
+                            pos_w[idp_w[lane]] = lane;
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < r) {
+                            rank = pos_w[lane];
+                            vs_w[rank] = val;
+                            fzp_w[rank] = fe;
+                        }
+                    }
+                    __syncthreads();
+                }
+
+                // ---- local_affect (:346-439): pi and d, then every variable ---------------
+                BXH_STAMP(13);
+                if (mine) {
+                    auto stale_at = [&](int pp) -> Float { // R[pp] as the rows in front left it
+                        for (int w = wave - 1; w >= 0; --w)
+                            if (t_re[s0 + w] - t_rs[s0 + w] > pp)
+                                return w_vs(w)[pp];
+                        return stale_s[pp <= pb.rmax ? pp : pb.rmax];
+                    };
+                    auto Rv = [&](int i) -> Float { return i < r ? vs_w[i] : stale_at(i); };
+                    const Float one = 1, two = 2;
+                    const Float middle = (two + one) / two;
+                    const Float old_pi = pi_s[k];
+                    Float new_pi;
+                    if (sel < 0)
+                        new_pi = old_pi + Rv(0) / two;
+                    else if (sel + 1 >= r)
+                        new_pi = old_pi + Rv(sel) * middle;
+                    else
+                        new_pi = old_pi + ((Rv(sel) + Rv(sel + 1)) / two);
+                    if (lane == 0) {
+                        pi_s[k] = new_pi;
+                        if (signbit(old_pi) != signbit(new_pi))
+                            atomicOr(&misc_s[MS_PICH], 1);
+                    }
+                    BXH_STAMP(1);
+                    const Float d = (kappa / (one - kappa)) + delta;
+                    if (lane < r) {
+                        const int j = c_desc.w;
+                        const int pe = c_desc.z;
+                        const bool up = sel < 0 ? false : (sel + 1 >= r ? true : rank <= sel);
+                        // (one walk of the column for both cases: the lanes of a wave take both)
+                        Float pp = up ? p_decayed + d : p_decayed - d;
+                        if (up)
+                            atomicOr(&x_s[j >> 5], 1u << (j & 31));
+                        else
+                            atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
+                        set_own(pp, new_pi);
+                        const Float repair = z_rc(pp, new_pi);
+                        if (up) {
+                            if (repair >= 0)
+                                pp = pp - repair + d;
+                        } else {
+                            if (repair <= 0)
+                                pp = pp + repair - d;
+                        }
+                        P[pe] = pp;
+                    }
+                    BXH_STAMP(2);
+                }
+                BXH_STAMP(14);
+                __syncthreads(); // B2: the group is done (P in memory, pi / x in LDS)
+                BXH_STAMP(15);
+                // R as the reference leaves it: the rows of the group wrote it in turn, so a
+                // position keeps the value of the LAST row long enough to reach it
+                if (mine) {
+                    int later = 0;
+                    for (int w = wave + 1; w < g; ++w)
+                        later = max(later, t_re[s0 + w] - t_rs[s0 + w]);
+                    if (lane < r && lane >= later)
+                        stale_s[lane] = vs_w[lane];
+                }
+                if (mine)
+                    alg_w += t_rb[sl]; // (lane 0 of the wave counts; summed at the end)
+                it += g - 1;
+                continue;
+            }
+            // the general path for this row (the table holds its scalars)
+            const int sl = it - tbase;
+            cur.k = t_k[sl];
+            cur.rs = t_rs[sl];
+            cur.re = t_re[sl];
+            cur.zk = t_z[sl];
+            cur.bmin = t_bmin[sl];
+            cur.bmax = t_bmax[sl];
+            cur.rbytes = t_rb[sl];
+            pre_ok = false;
+            __syncthreads(); // (the stale values the last group wrote)
+        } else {
+            if (it + 1 < nrows)
+                nxt = row_of(k_ahead);
+            if (it + 2 < nrows)
+                k_ahead = row_id(it + 2);
+        }
         const int k = cur.k;
         const int rs = cur.rs;
         const int r = cur.re - cur.rs;
@@ -2110,7 +2736,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         }
         // the next row's descriptors: on their way while this row is worked on
         pre_ok = false;
-        if (it + 1 < nrows && pb.q_ptr == nullptr && nxt.re - nxt.rs <= T) {
+        if (!ZW && it + 1 < nrows && pb.q_ptr == nullptr && nxt.re - nxt.rs <= T) {
             pre_ok = true;
             if (tid < nxt.re - nxt.rs) {
                 const int e = nxt.rs + tid;
@@ -2364,89 +2990,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
         }
         __syncthreads();
         const int submode = misc_s[MS_SELMODE];
-        if (submode == 1) {
-            if (tid == 0) {
-                if (!bb_search<Float>(val_s, id_s, fz_s, r, bkmin, bkmax, maximize, scratch, res_s))
-                    __hip_atomic_store(err_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-        } else if (submode == 2) {
-            // exhaustive_solver::solve, exhaustive-solver.hpp:185-252: the
-            // best of the row's precomputed feasible patterns, the first one
-            // among equals (one thread per pattern, sums in element order)
-            const int start = pb.ex_start[k], nsol = pb.ex_count[k];
-            if (tid == 0) {
-                key_s[0] = ~0ull;
-                misc_s[MS_CNT] = 0x7fffffff;
-            }
-            __syncthreads();
-            for (int t = tid; t < nsol; t += T) {
-                Float z = 0;
-                for (int jx = 0; jx < r; ++jx)
-                    if (pb.ex_flat[start + t * r + jx])
-                        z += val_s[id_s[jx]];
-                atomicMin(&key_s[0], order_key<Float>(z, maximize));
-            }
-            __syncthreads();
-            for (int t = tid; t < nsol; t += T) {
-                Float z = 0;
-                for (int jx = 0; jx < r; ++jx)
-                    if (pb.ex_flat[start + t * r + jx])
-                        z += val_s[id_s[jx]];
-                if (order_key<Float>(z, maximize) == key_s[0])
-                    atomicMin(&misc_s[MS_CNT], t);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                const int best = misc_s[MS_CNT];
-                for (int i = 0; i < r; ++i)
-                    res_s[i] = pb.ex_flat[start + best * r + i] ? 1 : 0;
-            }
-            __syncthreads();
-        }
-        if (submode != 0) {
-            // both sub-solvers end with a sort by (result first, then value)
-            // and return the split index (:219-252, :505-533)
-            if (tid == 0) {
-                int* tmp = (int*)key_s; // ids in the new order
-                int cnt1 = 0;
-                if (submode == 1) { // R is sorted by value: a stable partition
-                    for (int i = 0; i < r; ++i)
-                        if (res_s[i])
-                            tmp[cnt1++] = id_s[i];
-                    int z0 = cnt1;
-                    for (int i = 0; i < r; ++i)
-                        if (!res_s[i])
-                            tmp[z0++] = id_s[i];
-                } else { // at most 9 items: libstdc++'s insertion sort
-                    for (int i = 0; i < r; ++i) {
-                        tmp[i] = id_s[i];
-                        tmp[r + i] = res_s[i];
-                        cnt1 += res_s[i];
-                    }
-                    auto less = [&](int ia, int ra, int ib, int rb) -> bool {
-                        if (ra == rb)
-                            return maximize ? val_s[ia] > val_s[ib] : val_s[ia] < val_s[ib];
-                        return ra > rb;
-                    };
-                    for (int i = 1; i < r; ++i) {
-                        const int vi = tmp[i], vr = tmp[r + i];
-                        int jx = i;
-                        while (jx > 0 && less(vi, vr, tmp[jx - 1], tmp[r + jx - 1])) {
-                            tmp[jx] = tmp[jx - 1];
-                            tmp[r + jx] = tmp[r + jx - 1];
-                            --jx;
-                        }
-                        tmp[jx] = vi;
-                        tmp[r + jx] = vr;
-                    }
-                }
-                for (int i = 0; i < r; ++i)
-                    id_s[i] = tmp[i];
-                misc_s[MS_SEL] = cnt1 == r ? r : cnt1 - 1;
-            }
-            __syncthreads();
-        }
+        subsolve(submode, k, r, bkmin, bkmax, val_s, id_s, fz_s, res_s);
 
         BXH_STAMP(4);
         // ---- local_affect, :346-439: pi and d first ----------------------------
@@ -2555,6 +3099,14 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
             st.prof[(size_t)inst * 32 + i] += prof.acc[i];
 #endif
 
+    if (ZW) { // the rows the waves took by themselves
+        if (lane == 0)
+            t_rb[wave] = alg_w;
+        __syncthreads();
+        if (tid == 0)
+            for (int w = 0; w < NW; ++w)
+                alg_bytes += t_rb[w];
+    }
     if (tid == 0) {
         if (!keep)
             st.vcount[inst] = cnt;

@@ -186,6 +186,8 @@ def kernel_label(form):
         return "bxh::sweep_kernel_v2 (staged, 1 workgroup / instance)"
     if form == 3:
         return "bxh::sweep_kernel_z"
+    if form == 6:
+        return "bxh::sweep_kernel_z (a wave per row, up to 4 independent rows of an instance side by side)"
     if form == 5:
         return "bxh::sweep_kernel_narrow (short rows: one or four waves / instance)"
     if form > 100:

@@ -167,6 +167,9 @@ int bxh_rmax(bxh_handle h);
  *   1  lane-per-column walk, one workgroup per instance
  *   2  staged pipeline, one workgroup per instance
  *   3  inequalities-Z kernel
+ *   5  short-row kernel (one or four waves per instance)
+ *   6  inequalities-Z kernel, a wave per row: up to four rows of an instance that
+ *      share no column run side by side (linear objective)
  *   20 + g  staged pipeline, g lock-step column owners per instance
  *   40 + w  pipelined sweep, w workgroups per instance (1 row chain + w - 1 producers)
  *   100 + g wide kernel (columns / row counts beyond the staged kernel: the XL

@@ -117,7 +117,7 @@ def test_config_c5_z_matches_oracle(oracle, bxh, batch):
     inst = synth.config_c5("int")
     assert inst.kind == 4
     form = run_config(oracle, bxh, inst, batch, 1, sweeps=5 if batch == 256 else 8, push_at=(3,))
-    assert form == 3, form
+    assert form in (3, 6), form  # 6: the wave-per-row form of the Z kernel (linear objective)
 
 
 def bench_steps(oracle, bxh, batch, float_type, steps, p_every, expect_form=44, cost_kind="int"):
