@@ -787,6 +787,31 @@ flag_violated(const DevProblem& pb, const unsigned* x_s, signed char* vflag, int
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
     const bool pm1 = pb.kind == 2 || pb.kind == 3;
+    if ((long long)pb.nnz <= 64ll * pb.m) {
+        // Short rows: a THREAD per row, eight elements per round trip.  (A wave per row
+        // is two dependent loads of latency per row and wave -- 0.3 ms for 1000 rows of
+        // 40 elements, a twelfth of a sweep of the Z kernel -- with 60 idle lanes.)
+        for (int k = k0 + tid; k < k1; k += T) {
+            const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
+            int v = 0;
+            for (int e0 = rs; e0 < re; e0 += 8) {
+                int j8[8], f8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u < re ? e0 + u : rs;
+                    j8[u] = pb.row_col[e];
+                    f8[u] = pb.kind == 4 ? pb.fac32[e] : (pm1 ? (int)pb.fac_csr[e] : 1);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int bit = (x_s[j8[u] >> 5] >> (j8[u] & 31)) & 1u;
+                    v += e0 + u < re ? f8[u] * bit : 0;
+                }
+            }
+            vflag[k] = !(pb.bmin[k] <= v && v <= pb.bmax[k]);
+        }
+        return 0;
+    }
     for (int k = k0 + wave; k < k1; k += nwaves) {
         const int rs = pb.row_ptr[k], re = pb.row_ptr[k + 1];
         int v = 0;
@@ -1777,7 +1802,7 @@ zw_wave_bytes(int fsize)
 __host__ __device__ constexpr int
 zw_table_bytes()
 {
-    return ZW_TABLE * (8 * 4 + 8 + 8);
+    return ZW_TABLE * (8 * 4 + 8 + 8 + 2 * 16);
 }
 
 __host__ __device__ inline int
@@ -2010,7 +2035,10 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     int* const t_bmin = t_z + ZW_TABLE;
     int* const t_bmax = t_bmin + ZW_TABLE;
     int* const t_g = t_bmax + ZW_TABLE;  // rows of the group that starts at this slot (0: general path)
-    int* const t_cb = t_g + ZW_TABLE;    // bit u - 1: clashes with the row u slots back; bit 8: simple
+    int* const t_cb = t_g + ZW_TABLE;    // (spare)
+    // the scalars a group start reads, packed: {k, rs, re, kind} and {bmin, bmax, group size, r}
+    int4* const t_a = (int4*)(t_cb + ZW_TABLE);
+    int4* const t_b = t_a + ZW_TABLE;
     unsigned* const err_word = st.cnt + 2 * gridDim.x;
 
     const Float kappa = (Float)a.kappa[inst];
@@ -2217,6 +2245,9 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     };
     // the lane's element descriptor of its row in the NEXT group, fetched a group ahead
     double alg_w = 0.0; // algorithmic bytes of the rows this wave took
+    RowZ nf = { 0, 0, 0, 0, 0, 0, 0.0 }; // a row of the NEXT table, fetched a table ahead
+    unsigned long long nf_conf = 0ull;
+    int nf_pos = 0x7fffffff;
     int zp_pos = -1;
     int2 zp_cs = make_int2(0, 0);
     int zp_j = 0, zp_pe = 0, zp_f = 0;
@@ -2228,9 +2259,26 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
             if (it + 2 * NW > tbase + ZW_TABLE && (tbase < 0 || tbase + ZW_TABLE < nrows)) {
                 BXH_STAMP(7);
                 __syncthreads(); // (nobody reads the old table any more)
+                // (the rows of this table were fetched into registers when the last one was
+                // filled -- positions old tbase + 48 ..: thread t holds position nf_pos)
+                const bool have = tbase >= 0;
                 tbase = it;
-                if (tid < ZW_TABLE && it + tid < nrows) {
+                if (have) {
+                    const int sl_ = nf_pos - it;
+                    if (sl_ >= 0 && sl_ < ZW_TABLE && nf_pos < nrows) {
+                        t_k[sl_] = nf.k;
+                        t_rs[sl_] = nf.rs;
+                        t_re[sl_] = nf.re;
+                        t_z[sl_] = nf.zk;
+                        t_bmin[sl_] = nf.bmin;
+                        t_bmax[sl_] = nf.bmax;
+                        t_rb[sl_] = nf.rbytes;
+                        t_conf[sl_] = nf_conf;
+                        t_a[sl_] = make_int4(nf.k, nf.rs, nf.re, nf.zk);
+                    }
+                } else if (tid < ZW_TABLE && it + tid < nrows) {
                     const RowZ x = row_of(row_id(it + tid));
+                    t_a[tid] = make_int4(x.k, x.rs, x.re, x.zk);
                     t_k[tid] = x.k;
                     t_rs[tid] = x.rs;
                     t_re[tid] = x.re;
@@ -2279,21 +2327,29 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                         }
                     }
                     t_g[tid] = gs;
+                    t_b[tid] = make_int4(t_bmin[tid], t_bmax[tid], gs, t_re[tid] - t_rs[tid]);
+                }
+                // the rows of the NEXT table: on their way from now on
+                nf_pos = it + 48 + tid;
+                if (tid < 80 && nf_pos < nrows) {
+                    nf = row_of(row_id(nf_pos));
+                    nf_conf = pb.zconf[nf.k];
                 }
                 __syncthreads();
             }
-            const int g = __builtin_amdgcn_readfirstlane(t_g[it - tbase]);
+            const int g = __builtin_amdgcn_readfirstlane(t_b[it - tbase].z);
             if (g > 0) {
                 BXH_STAMP(8);
                 const int s0 = it - tbase;
                 const bool mine = wave < g;
                 const int sl = s0 + (mine ? wave : 0);
-                const int k = __builtin_amdgcn_readfirstlane(t_k[sl]);
-                const int rs = __builtin_amdgcn_readfirstlane(t_rs[sl]);
-                const int r = mine ? __builtin_amdgcn_readfirstlane(t_re[sl]) - rs : 0;
-                const int zk = __builtin_amdgcn_readfirstlane(t_z[sl]);
-                const int bkmin = __builtin_amdgcn_readfirstlane(t_bmin[sl]);
-                const int bkmax = __builtin_amdgcn_readfirstlane(t_bmax[sl]);
+                const int4 ta = t_a[sl], tb = t_b[sl];
+                const int k = __builtin_amdgcn_readfirstlane(ta.x);
+                const int rs = __builtin_amdgcn_readfirstlane(ta.y);
+                const int r = mine ? __builtin_amdgcn_readfirstlane(tb.w) : 0;
+                const int zk = __builtin_amdgcn_readfirstlane(ta.w);
+                const int bkmin = __builtin_amdgcn_readfirstlane(tb.x);
+                const int bkmax = __builtin_amdgcn_readfirstlane(tb.y);
                 Float* const val_w = w_val(wave);
                 Float* const vs_w = w_vs(wave);
                 unsigned long long* const key_w = w_key(wave);
@@ -2369,12 +2425,13 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                     const int pos2 = it + g;
                     zp_pos = -1;
                     if (pos2 < nrows && pos2 + NW <= tbase + ZW_TABLE) {
-                        const int g2 = __builtin_amdgcn_readfirstlane(t_g[pos2 - tbase]);
+                        const int g2 = __builtin_amdgcn_readfirstlane(t_b[pos2 - tbase].z);
                         if (wave < g2) {
                             const int sl2 = pos2 - tbase + wave;
-                            const int e2 = t_rs[sl2] + lane;
+                            const int4 ta2 = t_a[sl2];
+                            const int e2 = ta2.y + lane;
                             zp_pos = pos2 + wave;
-                            if (e2 < t_re[sl2]) {
+                            if (e2 < ta2.z) {
                                 zp_cs = pb.row_cs[e2];
                                 zp_j = pb.row_col[e2];
                                 zp_pe = pb.row_pos[e2];
