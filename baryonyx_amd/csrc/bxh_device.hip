@@ -293,6 +293,8 @@ struct bxh_handle_s
     DevBuf<unsigned char> q_factor;
     DevBuf<signed char> zkind;
     DevBuf<unsigned long long> zconf; // Z kernel: rows k + 1 .. k + 64 that share a column with row k
+    DevBuf<int4> zdesc;               // Z kernel, wave form: two 16-byte records per CSR element
+    DevBuf<int2> zcolrf;              // Z kernel, wave form: {row, |coefficient|} of every padded CSC slot
     int zwave = 0;                    // Z kernel: rows of up to 63 elements go wave per row (groups)
     DevBuf<unsigned char> zscratch;
     DevBuf<int> mcount, mrun, slist, vamt, sid;
@@ -1277,6 +1279,33 @@ bxh_create(const bxh_problem* pb,
         HIP_TRY(h->chain_rec.upload(rec));
     }
     HIP_TRY(h->row_cs.upload(row_cs)); // (behind the block above: it adds the gaps)
+    if (zsolver && h->zwave) {
+        // what a lane of the wave form needs of its element, in ONE run of 32 bytes
+        // ({first slot, padded length, own slot, column}, {coefficient, cost bits}) and of its
+        // column's slots in one array ({row, |a|}): few base pointers, few loads
+        std::vector<int4> zd(static_cast<size_t>(nnz) * 2);
+        for (int e = 0; e != nnz; ++e) {
+            const int j = pb->col[e];
+            zd[2 * static_cast<size_t>(e)] = make_int4(row_cs[e].x, row_cs[e].y & 0xffff, row_pos[e], j);
+            int lo = 0, hi = 0;
+            if (float_type == BXH_FLOAT) {
+                const float cf = static_cast<float>(pb->cost[j]);
+                std::memcpy(&lo, &cf, 4);
+            } else {
+                const double cd = pb->cost[j];
+                int two[2];
+                std::memcpy(two, &cd, 8);
+                lo = two[0];
+                hi = two[1];
+            }
+            zd[2 * static_cast<size_t>(e) + 1] = make_int4(fac32[e], lo, hi, 0);
+        }
+        HIP_TRY(h->zdesc.upload(zd));
+        std::vector<int2> rf(static_cast<size_t>(nnzp));
+        for (size_t q = 0; q != static_cast<size_t>(nnzp); ++q)
+            rf[q] = make_int2(col_row[q], col_fac[q]);
+        HIP_TRY(h->zcolrf.upload(rf));
+    }
     {
         std::vector<unsigned char> c;
         if (float_type == BXH_FLOAT)
@@ -1531,6 +1560,8 @@ bxh_create(const bxh_problem* pb,
     dp.ex_count = h->ex_count.p;
     dp.ex_flat = h->ex_flat.p;
     dp.zconf = h->zconf.p;
+    dp.zdesc = h->zdesc.p;
+    dp.zcolrf = h->zcolrf.p;
     dp.zwave = h->zwave;
     dp.bmin = h->bmin.p;
     dp.bmax = h->bmax.p;

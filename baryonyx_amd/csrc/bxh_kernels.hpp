@@ -74,6 +74,9 @@ struct DevProblem
     const int* ex_flat;        //         patterns: factor or 0 per element, row after row
     const unsigned long long* zconf; // [m] bit d - 1: row k + d shares a column with row k (d = 1 .. 64)
     int zwave;                 // 1: sweep_kernel_z<Float, true> (rows of up to 63 elements: a wave per row)
+    const int4* zdesc;         // [2 nnz] wave form: {first slot, padded length, own slot, column},
+                               //         {coefficient, cost bits (lo, hi), 0} of CSR element e
+    const int2* zcolrf;        // [nnzp]  wave form: {row, |coefficient|} of CSC slot q
     const int* bmin;           // [m] clamped as the Solver constructor does
     const int* bmax;           // [m]
     const int* bneg;           // [m] negative_factor (== c_size of the row)
@@ -2249,9 +2252,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     unsigned long long nf_conf = 0ull;
     int nf_pos = 0x7fffffff;
     int zp_pos = -1;
-    int2 zp_cs = make_int2(0, 0);
-    int zp_j = 0, zp_pe = 0, zp_f = 0;
-    Float zp_cost = 0;
+    int4 zp_d0 = make_int4(0, 0, 0, 0), zp_d1 = make_int4(0, 0, 0, 0);
 
     for (int it = 0; it < nrows; ++it) {
         RowZ cur = nxt;
@@ -2363,28 +2364,26 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 // writes is in this column -- the pi of the slots' rows, read from LDS ONCE;
                 // the repair pass only swaps in the row's own slot (new pi_k, new P).
                 Float c_p[16], c_f[16], c_pi[16];
-                int c_r[16];
+                int4 c_rf[8]; // {row, |a|} of two slots each, as loaded
                 int4 c_desc = make_int4(0, 0, 0, 0);
                 Float c_cost = 0;
                 int fe = 0;
                 if (lane < r) {
-                    int2 cs;
-                    int j, pe;
+                    int4 d1;
                     if (zp_pos == it + wave) { // fetched while the previous group was worked on
-                        cs = zp_cs;
-                        j = zp_j;
-                        pe = zp_pe;
-                        fe = zp_f;
-                        c_cost = zp_cost;
+                        c_desc = zp_d0;
+                        d1 = zp_d1;
                     } else {
                         const int e = rs + lane;
-                        cs = pb.row_cs[e];
-                        j = pb.row_col[e];
-                        pe = pb.row_pos[e];
-                        fe = pb.fac32[e];
-                        c_cost = cost[j];
+                        c_desc = pb.zdesc[2 * e];
+                        d1 = pb.zdesc[2 * e + 1];
                     }
-                    c_desc = make_int4(cs.x, cs.y & 0xffff, pe, j);
+                    fe = d1.x;
+                    if (sizeof(Float) == 8)
+                        c_cost = (Float)__hiloint2double(d1.z, d1.y);
+                    else
+                        c_cost = (Float)__int_as_float(d1.y);
+                    const int2 cs = make_int2(c_desc.x, c_desc.y);
                     // (columns are padded to 16 slots: 16-byte loads, all in flight together)
                     if (sizeof(Float) == 8) {
                         const double2* pv = reinterpret_cast<const double2*>((const double*)P + cs.x);
@@ -2405,20 +2404,10 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                             c_p[4 * u + 3] = (Float)t4.w;
                         }
                     }
-                    const int4* fv = reinterpret_cast<const int4*>(pb.col_fac + cs.x);
-                    const int4* rv = reinterpret_cast<const int4*>(pb.col_row + cs.x);
+                    const int4* rfv = reinterpret_cast<const int4*>(pb.zcolrf + cs.x);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int4 f4 = fv[u], r4 = rv[u];
-                        c_f[4 * u] = (Float)f4.x;
-                        c_f[4 * u + 1] = (Float)f4.y;
-                        c_f[4 * u + 2] = (Float)f4.z;
-                        c_f[4 * u + 3] = (Float)f4.w;
-                        c_r[4 * u] = r4.x;
-                        c_r[4 * u + 1] = r4.y;
-                        c_r[4 * u + 2] = r4.z;
-                        c_r[4 * u + 3] = r4.w;
-                    }
+                    for (int u = 0; u < 8; ++u)
+                        c_rf[u] = rfv[u]; // (used -- and so waited for -- only behind the prefetch below)
                 }
                 // the next group's descriptors: on their way while this one is worked on
                 {
@@ -2432,11 +2421,8 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                             const int e2 = ta2.y + lane;
                             zp_pos = pos2 + wave;
                             if (e2 < ta2.z) {
-                                zp_cs = pb.row_cs[e2];
-                                zp_j = pb.row_col[e2];
-                                zp_pe = pb.row_pos[e2];
-                                zp_f = pb.fac32[e2];
-                                zp_cost = cost[zp_j];
+                                zp_d0 = pb.zdesc[2 * e2];
+                                zp_d1 = pb.zdesc[2 * e2 + 1];
                             }
                         }
                     }
@@ -2464,8 +2450,9 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             p8[u] = P[qb + u];
-                            f8[u] = pb.col_fac[qb + u];
-                            r8[u] = pb.col_row[qb + u];
+                            const int2 rf = pb.zcolrf[qb + u];
+                            r8[u] = rf.x;
+                            f8[u] = rf.y;
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
@@ -2522,8 +2509,12 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 if (mine) {
                     if (lane < r) {
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) // (padding: any finite pi; its factor is 0)
-                            c_pi[u] = pi_s[c_r[u] < pb.m ? c_r[u] : 0];
+                        for (int u = 0; u < 8; ++u) { // (padding: any finite pi; its factor is 0)
+                            c_pi[2 * u] = pi_s[c_rf[u].x < pb.m ? c_rf[u].x : 0];
+                            c_pi[2 * u + 1] = pi_s[c_rf[u].z < pb.m ? c_rf[u].z : 0];
+                            c_f[2 * u] = (Float)c_rf[u].y;
+                            c_f[2 * u + 1] = (Float)c_rf[u].w;
+                        }
                         pik_old = pi_s[k];
                         p_decayed = z_own() * theta; // decrease_preference (stored with affect's value)
                         set_own(p_decayed, pik_old);
