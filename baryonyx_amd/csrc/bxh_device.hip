@@ -1059,8 +1059,17 @@ bxh_create(const bxh_problem* pb,
         }
         // wave-per-row groups (bxh_kernels.hpp: sweep_kernel_z<Float, true>): linear objective
         {
+            // (the wave form holds a column's slots, their pi and the next group's descriptors in
+            // registers: one workgroup per CU.  Beyond two workgroups per CU the plain form, two
+            // to a CU, is ahead again -- c5 at 1024 restarts: 112 against 76 M row-updates/s.)
             const char* ez = std::getenv("BXH_ZWAVE");
-            h->zwave = (pb->n_quad == 0 && !(ez && ez[0] == '0')) ? 1 : 0;
+            int cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+            h->zwave = (pb->n_quad == 0 && batch <= 2 * cus) ? 1 : 0;
+            if (ez)
+                h->zwave = (ez[0] != '0' && pb->n_quad == 0) ? 1 : 0;
             if (h->zwave &&
                 bxh::lds_bytes_z(m, h->nwords, rmax, static_cast<int>(h->fsize), true) > lds_limit)
                 h->zwave = 0;

@@ -75,7 +75,9 @@ def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweep
             assert st["rng"][b] == s.rng, tag + " rng"
             assert st["row_updates"][b] == s.row_updates, tag + " row_updates"
         kappa = kappa + 0.02
+    form = dev.kernel_form
     dev.close()
+    return form
 
 
 @pytest.mark.parametrize("groups", ["1", "2", "4", "p2", "p4"])
@@ -240,13 +242,32 @@ Z_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", Z_CASES, ids=[c[0] for c in Z_CASES])
-def test_z_sweeps_match_oracle(oracle, bxh, case):
+Z_WAVE_CASES = [
+    # rows short enough for the wave-per-row form, few enough columns for neighbours to clash
+    # and many enough for groups of two to four rows; integer costs: tied rows draw from the
+    # engine in row order; the rows of kinds 0 / 1 and the long ones go the general way in between
+    ("z-wave-int", lambda: synth.make_z(120, 900, 0.03, "int", 71), 1, False, 0, 0.0),
+    ("z-wave-real-max", lambda: synth.make_z(100, 600, 0.04, "real", 72), 1, True, 1, 0.2),
+    ("z-wave-f32-random-order", lambda: synth.make_z(150, 1200, 0.025, "int", 73), 0, False, 2, 0.1),
+    ("z-wave-mixed-kinds", lambda: synth.make_zmix(80, 400, "int", 74, maxlen=14, maximize=True), 1, True, 0, 0.1),
+    ("z-wave-mixed-kinds-min", lambda: synth.make_zmix(90, 500, "real", 75, maxlen=16, maximize=False), 1, False, 0, 0.3),
+    ("z-wave-long-list", lambda: synth.make_z(400, 2500, 0.012, "int", 76), 1, False, 0, 0.0),
+]
+
+
+@pytest.mark.parametrize("zwave", ["wave-per-row", "plain"])
+@pytest.mark.parametrize("case", Z_CASES + Z_WAVE_CASES, ids=[c[0] for c in Z_CASES + Z_WAVE_CASES])
+def test_z_sweeps_match_oracle(oracle, bxh, case, zwave, monkeypatch):
     """inequalities-Z (general integer coefficients): linear scan, branch and
     bound, exhaustive patterns and their `unconstrained` variants, followed by
-    local_affect's repair pass (itm-solver-inequalities-Z.cpp:295-564)."""
+    local_affect's repair pass (itm-solver-inequalities-Z.cpp:295-564) -- in the
+    kernel's two forms: a wave per row with independent neighbours of the list side
+    by side (what a linear objective gets up to two workgroups per CU), and the
+    plain one (BXH_ZWAVE=0: larger batches, quadratic objectives)."""
+    monkeypatch.setenv("BXH_ZWAVE", "1" if zwave == "wave-per-row" else "0")
     _, maker, float_type, maximize, order, x0p = case
-    run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
+    form = run_case(oracle, bxh, maker(), float_type, maximize, order, x0p)
+    assert form == (6 if zwave == "wave-per-row" else 3), form
 
 
 def with_quadratic(inst, seed, terms):
