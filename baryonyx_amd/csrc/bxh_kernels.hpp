@@ -2430,20 +2430,22 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 // sum over the lane's column as the cached arrays stand (set_own puts the row's own
                 // entry -- pi_k and the not yet stored P -- into its slot first): the cached slots,
                 // then (columns of more than 16 entries) the rest
+                // (c_pi holds pi + P of every slot once phase A has formed the sums: the reference
+                // adds `a * (pi + P)` slot after slot, so the inner sum can be kept instead of its
+                // two terms -- half the registers, half the selects of the own slot)
                 auto set_own = [&](Float pown, Float pik) {
                     const int off = c_desc.z - c_desc.x;
+                    const Float so = pik + pown;
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        c_p[u] = u == off ? pown : c_p[u];
-                        c_pi[u] = u == off ? pik : c_pi[u];
-                    }
+                    for (int u = 0; u < 16; ++u)
+                        c_pi[u] = u == off ? so : c_pi[u];
                 };
                 auto z_rc = [&](Float pown, Float pik) -> Float {
                     Float acc = 0;
                     const int q0 = c_desc.x, pe = c_desc.z;
 #pragma unroll
                     for (int u = 0; u < 16; ++u)
-                        acc += c_f[u] * (c_pi[u] + c_p[u]);
+                        acc += c_f[u] * c_pi[u];
                     for (int qb = q0 + 16; qb < q0 + c_desc.y; qb += 8) {
                         Float p8[8], pi8[8];
                         int f8[8], r8[8];
@@ -2517,6 +2519,9 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                         }
                         pik_old = pi_s[k];
                         p_decayed = z_own() * theta; // decrease_preference (stored with affect's value)
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            c_pi[u] = c_pi[u] + c_p[u]; // pi + P, as the reference adds them
                         set_own(p_decayed, pik_old);
                         val = z_rc(p_decayed, pik_old);
                         if (push) // :467-469: the true column
