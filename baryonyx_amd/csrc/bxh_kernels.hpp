@@ -2366,7 +2366,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 Float c_p[16], c_f[16], c_pi[16];
                 int4 c_rf[8]; // {row, |a|} of two slots each, as loaded
                 int4 c_desc = make_int4(0, 0, 0, 0);
-                Float c_cost = 0;
+                Float c_cost = 0, p_own_raw = 0;
                 int fe = 0;
                 if (lane < r) {
                     int4 d1;
@@ -2408,6 +2408,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
                         c_rf[u] = rfv[u]; // (used -- and so waited for -- only behind the prefetch below)
+                    p_own_raw = P[c_desc.z]; // (one more load instead of sixteen selects)
                 }
                 // the next group's descriptors: on their way while this one is worked on
                 {
@@ -2467,17 +2468,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                     }
                     return c_cost - acc;
                 };
-                auto z_own = [&]() -> Float { // P[pe] as it stands in memory
-                    const int off = c_desc.z - c_desc.x;
-                    Float v = 0;
-                    if (off < 16) {
-#pragma unroll
-                        for (int u = 0; u < 16; ++u)
-                            v = u == off ? c_p[u] : v;
-                    } else
-                        v = P[c_desc.z];
-                    return v;
-                };
+                auto z_own = [&]() -> Float { return p_own_raw; }; // P[pe] as it stands in memory
                 Float val = 0;
                 unsigned long long key = ~0ull;
                 int rank = 0;
