@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0,
-                    help="restarts per GPU (0: 64, or what fits in HBM for c4)")
+                    help="restarts per GPU (0: 64; 256 for c5; what fits in HBM for c4)")
     ap.add_argument("--float", dest="float_kind", choices=["double", "float"], default="double")
     ap.add_argument("--cost-kind", choices=["int", "real"], default="int")
     ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c2")
@@ -408,7 +408,8 @@ class StdWorkload:
         self.params = Params()
         cost = normalize_costs(inst.dense_costs(), self.params.cost_norm, float_type)
         self.delta = compute_delta(cost, self.params.theta, float_type)
-        self.batch = args.batch if args.batch > 0 else 64
+        # (BASELINE.json: configs[1] names 64 restarts per GPU, configs[4] -- c5 -- 256)
+        self.batch = args.batch if args.batch > 0 else (256 if args.config == "c5" else 64)
         self.dev = _ffi.DeviceBatch(inst, cost, self.batch, float_type=float_type, device=local_rank)
         self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
         for b in range(self.batch):  # one std engine per worker, distinct seeds
