@@ -67,7 +67,7 @@ def test_z_forms_on_random_instances(oracle, bxh, seed, zwave, monkeypatch):
     m = 90 + 37 * (seed % 4)
     n = [260, 700, 1500][seed % 3]
     inst = make_zfuzz(900 + seed, m, n, maximize=bool(seed & 1))
-    order = [0, 0, 1, 2, 0, 5][seed % 6]
+    order = [0, 3, 1, 2, 4, 5, 0, 6, 0, 2, 1, 0][seed]  # (pi_sign_change / cycle need n <= m)
     form = run_case(oracle, bxh, inst, float_type=1 if seed % 5 else 0, maximize=bool(seed & 1), order=order,
                     x0p=[0.0, 0.2, 0.5][seed % 3], batch=2, sweeps=8, push_at=(4,))
     assert form == (6 if zwave == "1" else 3)
