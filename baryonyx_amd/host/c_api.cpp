@@ -144,6 +144,36 @@ make_ctx(const bxc_params* p)
     return ctx;
 }
 
+// context_set_solver_parameters + context_get_solver_parameters: what the solvers will see of
+// `in` after the range checks of lib/src/private.cpp:50-172 (tests).
+BX_EXPORT void
+bxc_validated_params(const bxc_params* in, bxc_params* out)
+{
+    auto ctx = make_ctx(in);
+    const solver_parameters q = context_get_solver_parameters(ctx);
+    *out = *in;
+    out->time_limit = q.time_limit;
+    out->theta = q.theta;
+    out->delta = q.delta;
+    out->kappa_min = q.kappa_min;
+    out->kappa_step = q.kappa_step;
+    out->kappa_max = q.kappa_max;
+    out->alpha = q.alpha;
+    out->pushing_k_factor = q.pushing_k_factor;
+    out->pushing_objective_amplifier = q.pushing_objective_amplifier;
+    out->init_policy_random = q.init_policy_random;
+    out->w = q.w;
+    out->limit = q.limit;
+    out->seed = q.seed;
+    out->thread = q.thread;
+    out->pushes_limit = q.pushes_limit;
+    out->pushing_iteration_limit = q.pushing_iteration_limit;
+    out->init_population_size = q.init_population_size;
+    out->order = static_cast<int>(q.order);
+    out->init_policy = static_cast<int>(q.init_policy);
+    out->cost_norm = static_cast<int>(q.cost_norm);
+}
+
 // make_problem on a file; fills `info`.
 BX_EXPORT int
 bxc_parse(const char* path, bxc_problem_info* info)

@@ -145,3 +145,41 @@ def test_cost_ratio_row_orders_p1_p2(tmp_path):
         assert inst.m == 3 and inst.n == 4
         rows = [tuple(int(j) for j in inst.col[inst.row_ptr[k]:inst.row_ptr[k + 1]]) for k in range(3)]
         assert rows == expect, (order, rows)
+
+
+def test_parameter_validation_matches_the_restatement():
+    """context_set_solver_parameters of the host library (lib/src/private.cpp:50-172
+    restated in host/api.cpp) against the tests' own restatement (helpers.validated_params,
+    what the oracle-side reference tests run with): same fields for a spread of raw values,
+    incl. the reference tests' out-of-range kappa triples, `limit = -1` and fractional `w`."""
+    import ctypes as C
+    import itertools
+    import math
+
+    from helpers import validated_params
+    L = H.lib()
+    L.bxc_validated_params.argtypes = [C.POINTER(H.Params), C.POINTER(H.Params)]
+    grid = dict(
+        limit=[-1, 0, 50, 1000],
+        w=[-1.0, 0.05, 0.5, 20.0, 5000.0],
+        kappa=[(0.0, 1e-3, 0.6), (0.3, 1e-2, 100.0), (0.1, 1e-17, 1.0), (0.5, 0.1, 0.4), (-0.1, 0.1, 0.5),
+               (0.0, 1.0, 0.6)],
+        theta=[0.5, 1.5], delta=[-1.0, 0.2, -0.5], alpha=[1.0, -2.0],
+    )
+    fields = ("theta delta kappa_min kappa_step kappa_max alpha w limit pushes_limit "
+              "pushing_iteration_limit init_population_size").split()
+    count = 0
+    for limit, w, (kmin, kstep, kmax), theta, delta, alpha in itertools.product(*grid.values()):
+        raw = dict(limit=limit, w=w, kappa_min=kmin, kappa_step=kstep, kappa_max=kmax, theta=theta,
+                   delta=delta, alpha=alpha, pushes_limit=-3 if count % 2 else 7,
+                   pushing_iteration_limit=0 if count % 3 else 11, init_population_size=3 if count % 5 else 40)
+        want = validated_params(**raw)
+        got = H.Params()
+        L.bxc_validated_params(C.byref(H.default_params(**raw)), C.byref(got))
+        for f in fields:
+            a, b = getattr(got, f), want[f]
+            if f == "limit":
+                b = min(b, 2 ** 63 - 1)
+            assert a == b or (isinstance(b, float) and math.isinf(b) and math.isinf(a)), (raw, f, a, b)
+        count += 1
+    assert count == 4 * 5 * 6 * 2 * 3 * 2
