@@ -8,6 +8,7 @@
 #include "bxh_kernels.hpp"
 #include "bxh_wide.hpp"
 #include "bxh_narrow.hpp"
+#include "bxh_swave.hpp"
 #include "bxh_wide_build.hpp"
 
 #include <algorithm>
@@ -119,6 +120,10 @@ set_lds_limits(int device)
     BXH_SET_LDS(bxh::sweep_kernel<double, true>);
     BXH_SET_LDS(bxh::sweep_kernel_z<float, false>);
     BXH_SET_LDS(bxh::sweep_kernel_z<double, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_sw<float, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_sw<float, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_sw<double, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_sw<double, true>);
     BXH_SET_LDS(bxh::sweep_kernel_z<float, true>);
     BXH_SET_LDS(bxh::sweep_kernel_z<double, true>);
     BXH_SET_LDS(bxh::order_post_kernel<float>);
@@ -296,6 +301,7 @@ struct bxh_handle_s
     DevBuf<int4> zdesc;               // Z kernel, wave form: two 16-byte records per CSR element
     DevBuf<int2> zcolrf;              // Z kernel, wave form: {row, |coefficient|} of every padded CSC slot
     int zwave = 0;                    // Z kernel: rows of up to 63 elements go wave per row (groups)
+    int swave = 0;                    // 01 / 101 solvers, every row of 1 .. 63 elements: a wave per row (version 7)
     DevBuf<unsigned char> zscratch;
     DevBuf<int> mcount, mrun, slist, vamt, sid;
     DevBuf<unsigned long long> skey;
@@ -491,6 +497,11 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
             BXH_LAUNCH((bxh::sweep_kernel_z<Float, true>));
         else
             BXH_LAUNCH((bxh::sweep_kernel_z<Float, false>));
+    } else if (h->version == 7) {
+        if (pm1)
+            BXH_LAUNCH((bxh::sweep_kernel_sw<Float, true>));
+        else
+            BXH_LAUNCH((bxh::sweep_kernel_sw<Float, false>));
     } else if (h->version == 5) {
 #define BXH_NARROW(PM, WW, RQ)                                                 \
     hipLaunchKernelGGL((bxh::sweep_kernel_narrow<Float, PM, WW, RQ>), dim3(h->batch), dim3(64 * WW), \
@@ -671,6 +682,26 @@ bxh_create(const bxh_problem* pb,
     // CU.  Rows of at most 256 elements, columns of a few 16-entry pieces, linear
     // objective, 01 / 101 solvers; BXH_NARROW=0 keeps the staged kernel, =1 takes
     // the narrow one for any column length the staged kernel would take.
+    // ... and where every row has 1 .. 63 elements, a wave per row with independent rows of the list
+    // side by side (bxh_swave.hpp; up to two workgroups per CU, linear objective).  BXH_SWAVE=0 / 1.
+    bool swave = false;
+    {
+        int rmin = m > 0 ? rmax : 0;
+        for (int k = 0; k != m; ++k)
+            rmin = std::min(rmin, pb->row_ptr[k + 1] - pb->row_ptr[k]);
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        const char* es = std::getenv("BXH_SWAVE");
+        const bool fits = !zsolver && !wide_g && pb->n_quad == 0 && rmin >= 1 && rmax <= 63 && m >= 1 &&
+                          bxh::sw_lds(m, h->nwords, rmax, float_type == BXH_FLOAT ? 4 : 8).total <= 160 * 1024 &&
+                          !std::getenv("BXH_GROUPS") && !(force_v1 && force_v1[0] == '1');
+        // (by itself where the list is long enough for the groups to count and the one launch per
+        // sweep not to: the short-row kernel runs many sweeps of a small instance in one launch,
+        // bxh_run; beyond two workgroups per CU the one-wave kernel is ahead again)
+        swave = fits && (es ? es[0] == '1' : (m >= 64 && batch <= 2 * cus));
+    }
     bool narrow = false;
     {
         const char* en = std::getenv("BXH_NARROW");
@@ -678,10 +709,10 @@ bxh_create(const bxh_problem* pb,
         const bool off = (en && en[0] == '0') || std::getenv("BXH_GROUPS") || (force_v1 && force_v1[0] == '1');
         const int rpq = (rmax + 63) / 64;
         const int nl = bxh::narrow_lds(m, n, h->nwords, rmax, float_type == BXH_FLOAT ? 4 : 8, rpq).total;
-        narrow = !wide_g && !zsolver && pb->n_quad == 0 && rmax <= 256 && cmax <= 128 && m < 32767 &&
+        narrow = !swave && !wide_g && !zsolver && pb->n_quad == 0 && rmax <= 256 && cmax <= 128 && m < 32767 &&
                  nl <= 160 * 1024 && !off && (asked || cmax <= 32);
     }
-    const bool v2_ok = !narrow && !wide_g && !zsolver && cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
+    const bool v2_ok = !swave && !narrow && !wide_g && !zsolver && cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
     int groups = 1;
     if (v2_ok) {
         int cus = 256;
@@ -1138,6 +1169,12 @@ bxh_create(const bxh_problem* pb,
         h->lds_bytes = static_cast<size_t>(wl.total);
         h->lds_bytes_init = 0;
     }
+    if (swave) {
+        h->version = 7;
+        h->swave = 1;
+        h->threads = 256;
+        h->lds_bytes = static_cast<size_t>(bxh::sw_lds(m, h->nwords, rmax, static_cast<int>(h->fsize)).total);
+    }
     if (narrow) {
         h->version = 5;
         h->threads = 64;
@@ -1204,6 +1241,8 @@ bxh_create(const bxh_problem* pb,
         HIP_TRY(h->fac32.upload(fac32));
         HIP_TRY(h->col_fac.upload(col_fac));
         HIP_TRY(h->zkind.upload(zkind));
+    }
+    if (zsolver || swave) {
         {
             // bit d - 1 of zconf[k]: row k + d holds a column of row k (d = 1 .. 64).  Rows
             // that share no column commute exactly (neither reads what the other writes), so
@@ -1226,6 +1265,8 @@ bxh_create(const bxh_problem* pb,
                 }
             HIP_TRY(h->zconf.upload(conf));
         }
+    }
+    if (zsolver) {
         HIP_TRY(h->ex_start.upload(ex_start));
         HIP_TRY(h->ex_count.upload(ex_count));
         HIP_TRY(h->ex_flat.upload(ex_flat));
@@ -1288,7 +1329,7 @@ bxh_create(const bxh_problem* pb,
         HIP_TRY(h->chain_rec.upload(rec));
     }
     HIP_TRY(h->row_cs.upload(row_cs)); // (behind the block above: it adds the gaps)
-    if (zsolver && h->zwave) {
+    if ((zsolver && h->zwave) || swave) {
         // what a lane of the wave form needs of its element, in ONE run of 32 bytes
         // ({first slot, padded length, own slot, column}, {coefficient, cost bits}) and of its
         // column's slots in one array ({row, |a|}): few base pointers, few loads
@@ -1307,12 +1348,18 @@ bxh_create(const bxh_problem* pb,
                 lo = two[0];
                 hi = two[1];
             }
-            zd[2 * static_cast<size_t>(e) + 1] = make_int4(fac32[e], lo, hi, 0);
+            zd[2 * static_cast<size_t>(e) + 1] = make_int4(zsolver ? fac32[e] : (pb->factor ? pb->factor[e] : 1), lo, hi, 0);
         }
         HIP_TRY(h->zdesc.upload(zd));
         std::vector<int2> rf(static_cast<size_t>(nnzp));
-        for (size_t q = 0; q != static_cast<size_t>(nnzp); ++q)
-            rf[q] = make_int2(col_row[q], col_fac[q]);
+        for (size_t q = 0; q != static_cast<size_t>(nnzp); ++q) {
+            if (zsolver)
+                rf[q] = make_int2(col_row[q], col_fac[q]);
+            else { // 01 / 101: the row without its sign flag, the coefficient itself (0 in the padding)
+                const int rq = col_row[q] & 0x3fffffff;
+                rf[q] = make_int2(rq, rq >= m ? 0 : ((col_row[q] & 0x40000000) ? -1 : 1));
+            }
+        }
         HIP_TRY(h->zcolrf.upload(rf));
     }
     {
@@ -1997,6 +2044,8 @@ bxh_kernel_form(bxh_handle h)
         return BXH_ERR_INVALID;
     if (h->version == 3)
         return h->zwave ? 6 : 3;
+    if (h->version == 7)
+        return 7;
     if (h->version == 4)
         return 100 + h->wide_g;
     if (h->version == 5)

@@ -190,6 +190,8 @@ def kernel_label(form):
         return "bxh::sweep_kernel_z (a wave per row, up to 4 independent rows of an instance side by side)"
     if form == 5:
         return "bxh::sweep_kernel_narrow (short rows: one or four waves / instance)"
+    if form == 7:
+        return "bxh::sweep_kernel_sw (short rows: a wave per row, up to 4 independent rows of an instance side by side)"
     if form > 100:
         return f"bxh::sweep_kernel_wide ({form - 100} workgroups / instance share every row)"
     if 20 < form < 40:

@@ -170,6 +170,7 @@ int bxh_rmax(bxh_handle h);
  *   5  short-row kernel (one or four waves per instance)
  *   6  inequalities-Z kernel, a wave per row: up to four rows of an instance that
  *      share no column run side by side (linear objective)
+ *   7  01 / 101 solvers, every row of at most 63 elements: the same wave-per-row form
  *   20 + g  staged pipeline, g lock-step column owners per instance
  *   40 + w  pipelined sweep, w workgroups per instance (1 row chain + w - 1 producers)
  *   100 + g wide kernel (columns / row counts beyond the staged kernel: the XL

@@ -30,6 +30,7 @@ def narrow_env(request, monkeypatch):
     monkeypatch.delenv("BXH_GROUPS", raising=False)
     monkeypatch.delenv("BXH_FORCE_V1", raising=False)
     monkeypatch.setenv("BXH_NARROW", "1")
+    monkeypatch.setenv("BXH_SWAVE", "0")  # (the wave-per-row form would take the rows of up to 63 elements)
     monkeypatch.setenv("BXH_NARROW_W", request.param)
 
 
@@ -103,7 +104,12 @@ def test_narrow_baseline_shapes_many_instances(oracle, bxh, name, monkeypatch):
     """scp41 / aa04 shapes with 70 instances (more waves than one per CU on a
     quarter of the chip), and the kernel chosen by bxh_create itself."""
     monkeypatch.delenv("BXH_NARROW", raising=False)
+    monkeypatch.delenv("BXH_SWAVE", raising=False)
     inst = synth.config_c1("int") if name == "c1" else synth.config_c3("int")
+    # (scp41's rows have at most 35 elements: the wave-per-row form, bxh_swave.hpp; aa04's up to 150)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=70, sweeps=4, push_at=(2,),
+             expect_form=7 if name == "c1" else 5)
+    monkeypatch.setenv("BXH_SWAVE", "0")
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=70, sweeps=4, push_at=(2,), expect_form=5)
 
 
