@@ -699,8 +699,11 @@ bxh_create(const bxh_problem* pb,
                           !std::getenv("BXH_GROUPS") && !(force_v1 && force_v1[0] == '1');
         // (by itself where the list is long enough for the groups to count and the one launch per
         // sweep not to: the short-row kernel runs many sweeps of a small instance in one launch,
-        // bxh_run; beyond two workgroups per CU the one-wave kernel is ahead again)
-        swave = fits && (es ? es[0] == '1' : (m >= 64 && batch <= 2 * cus));
+        // bxh_run.  164 registers: three workgroups share a CU, and the form stays ahead of the
+        // one-wave kernel at every batch size measured -- c1 at 512 / 1024 / 2048 restarts
+        // 249 / 272 / 341 against 135 / 264 / 275 M row-updates/s)
+        (void)cus;
+        swave = fits && (es ? es[0] == '1' : m >= 64);
     }
     bool narrow = false;
     {
