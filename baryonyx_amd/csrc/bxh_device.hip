@@ -694,7 +694,7 @@ bxh_create(const bxh_problem* pb,
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
         const char* es = std::getenv("BXH_SWAVE");
-        const bool fits = !zsolver && !wide_g && pb->n_quad == 0 && rmin >= 1 && rmax <= 63 && m >= 1 &&
+        const bool fits = !zsolver && !wide_g && pb->n_quad == 0 && rmin >= 1 && rmax <= 63 && m >= 1 && m < 32768 &&
                           bxh::sw_lds(m, h->nwords, rmax, float_type == BXH_FLOAT ? 4 : 8).total <= 160 * 1024 &&
                           !std::getenv("BXH_GROUPS") && !(force_v1 && force_v1[0] == '1');
         // (by itself where the list is long enough for the groups to count and the one launch per
@@ -1351,7 +1351,8 @@ bxh_create(const bxh_problem* pb,
                 lo = two[0];
                 hi = two[1];
             }
-            zd[2 * static_cast<size_t>(e) + 1] = make_int4(zsolver ? fac32[e] : (pb->factor ? pb->factor[e] : 1), lo, hi, 0);
+            zd[2 * static_cast<size_t>(e) + 1] =
+              make_int4(zsolver ? fac32[e] : (pb->factor ? pb->factor[e] : 1), lo, hi, col_len[j]); // (.w: the column's real entries)
         }
         HIP_TRY(h->zdesc.upload(zd));
         std::vector<int2> rf(static_cast<size_t>(nnzp));

@@ -75,7 +75,7 @@ struct DevProblem
     const unsigned long long* zconf; // [m] bit d - 1: row k + d shares a column with row k (d = 1 .. 64)
     int zwave;                 // 1: sweep_kernel_z<Float, true> (rows of up to 63 elements: a wave per row)
     const int4* zdesc;         // [2 nnz] wave form: {first slot, padded length, own slot, column},
-                               //         {coefficient, cost bits (lo, hi), 0} of CSR element e
+                               //         {coefficient, cost bits (lo, hi), real entries of the column} of CSR element e
     const int2* zcolrf;        // [nnzp]  wave form: {row, |coefficient|} of CSC slot q
     const int* bmin;           // [m] clamped as the Solver constructor does
     const int* bmax;           // [m]

@@ -102,6 +102,13 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
 
     MinStd rng;
     rng.s = st.status[inst].rng; // meaningful in thread 0 only
+    Prof prof;
+    (void)prof;
+#ifdef BXH_PROFILE
+    for (int i = 0; i < 16; ++i)
+        prof.acc[i] = 0;
+    prof.t = wall_clock64();
+#endif
     const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
     double alg_w = 0.0; // algorithmic bytes of the rows this wave took (lane 0 counts)
 
@@ -139,6 +146,7 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
     };
 
     int tbase = -0x40000000; // list position of table slot 0
+    BXH_PSTAMP(&prof, 0);
     for (int it = 0; it < nrows;) {
         // ---- the table of the next 64 rows of the list, and their groups -------------
         if (it + 2 * NW > tbase + ZW_TABLE && (tbase < 0 || tbase + ZW_TABLE < nrows)) {
@@ -226,53 +234,65 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
         int* const pos_w = w_pos(wave);
 
         // ---- phase A: the lane's column -> reduced cost -> position -------------------
+        BXH_PSTAMP(&prof, 1);
+        // Only as much of the columns as the row's longest one holds is fetched: `nq` quads of
+        // four slots, wave-uniform (the slots behind a column's last entry are padding, P = +0.0
+        // and the row m whose pi is +0.0: leaving their additions out changes no bit of a sum
+        // that started at +0.0).  The rows of the slots come as 16-bit ids (bit 15: coefficient -1).
         Float c_p[16];
-        int4 c_rf[8]; // {row, a} of two slots each, as loaded
+        uint4 c_id[2] = { make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u) };
         int4 c_desc = make_int4(0, 0, 0, 0);
         Float c_cost = 0, p_own_raw = 0, c_push = 0;
-        int fe = 1;
-        if (lane < r) {
-            int4 d1;
-            if (zp_pos == it + wave) { // fetched while the previous group was worked on
-                c_desc = zp_d0;
-                d1 = zp_d1;
-            } else {
-                const int e = rs + lane;
-                c_desc = pb.zdesc[2 * e];
-                d1 = pb.zdesc[2 * e + 1];
-            }
-            fe = d1.x;
-            if (sizeof(Float) == 8)
-                c_cost = (Float)__hiloint2double(d1.z, d1.y);
-            else
-                c_cost = (Float)__int_as_float(d1.y);
-            const int q0 = c_desc.x;
-            if (sizeof(Float) == 8) {
-                const double2* pv = reinterpret_cast<const double2*>((const double*)P + q0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double2 t2 = pv[u];
-                    c_p[2 * u] = (Float)t2.x;
-                    c_p[2 * u + 1] = (Float)t2.y;
-                }
-            } else {
-                const float4* pv = reinterpret_cast<const float4*>((const float*)P + q0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 t4 = pv[u];
-                    c_p[4 * u] = (Float)t4.x;
-                    c_p[4 * u + 1] = (Float)t4.y;
-                    c_p[4 * u + 2] = (Float)t4.z;
-                    c_p[4 * u + 3] = (Float)t4.w;
+        int fe = 1, nq = 1;
+        {
+            int4 d1 = make_int4(1, 0, 0, 0);
+            if (lane < r) {
+                if (zp_pos == it + wave) { // fetched while the previous group was worked on
+                    c_desc = zp_d0;
+                    d1 = zp_d1;
+                } else {
+                    const int e = rs + lane;
+                    c_desc = pb.zdesc[2 * e];
+                    d1 = pb.zdesc[2 * e + 1];
                 }
             }
-            const int4* rfv = reinterpret_cast<const int4*>(pb.zcolrf + q0);
+            const int clen = lane < r ? d1.w : 0; // real entries of the lane's column
+            nq = __ballot(clen > 12) ? 4 : (__ballot(clen > 8) ? 3 : (__ballot(clen > 4) ? 2 : 1));
+            const bool far_own = __ballot(lane < r && c_desc.z - c_desc.x >= 16) != 0ull;
+            if (lane < r) {
+                fe = d1.x;
+                if (sizeof(Float) == 8)
+                    c_cost = (Float)__hiloint2double(d1.z, d1.y);
+                else
+                    c_cost = (Float)__int_as_float(d1.y);
+                const int q0 = c_desc.x;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                c_rf[u] = rfv[u];
-            p_own_raw = P[c_desc.z];
-            if (push && !PM1) // the 01 solvers amplify by the cost of variable number <local id> (quirk)
-                c_push = cost[lane];
+                for (int qd = 0; qd < 4; ++qd)
+                    if (qd < nq) {
+                        if (sizeof(Float) == 8) {
+                            const double2* pv = reinterpret_cast<const double2*>((const double*)P + q0);
+                            const double2 t0 = pv[2 * qd], t1 = pv[2 * qd + 1];
+                            c_p[4 * qd] = (Float)t0.x;
+                            c_p[4 * qd + 1] = (Float)t0.y;
+                            c_p[4 * qd + 2] = (Float)t1.x;
+                            c_p[4 * qd + 3] = (Float)t1.y;
+                        } else {
+                            const float4 t4 = reinterpret_cast<const float4*>((const float*)P + q0)[qd];
+                            c_p[4 * qd] = (Float)t4.x;
+                            c_p[4 * qd + 1] = (Float)t4.y;
+                            c_p[4 * qd + 2] = (Float)t4.z;
+                            c_p[4 * qd + 3] = (Float)t4.w;
+                        }
+                    }
+                const uint4* idv = reinterpret_cast<const uint4*>(pb.col_row16 + q0);
+                c_id[0] = idv[0];
+                if (nq > 2)
+                    c_id[1] = idv[1];
+                if (far_own) // (an own entry among the first 16 is taken out of the line below)
+                    p_own_raw = P[c_desc.z];
+                if (push && !PM1) // the 01 solvers amplify by the cost of variable number <local id> (quirk)
+                    c_push = cost[lane];
+            }
         }
         { // the next group's descriptors: on their way while this one is worked on
             const int pos2 = it + g;
@@ -290,6 +310,7 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
                 }
             }
         }
+        BXH_PSTAMP(&prof, 2);
         Float val = 0, p_decayed = 0;
         unsigned long long key = ~0ull;
         int rank = 0, sel = -1;
@@ -298,27 +319,40 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
             if (lane < r) {
                 // decrease_preference + compute_reduced_costs: two sums in CSC order, the row's own
                 // entry decayed (it reaches memory with affect's value)
-                p_decayed = p_own_raw * theta;
                 const int off = c_desc.z - c_desc.x;
-                Float sum_a_pi = 0, sum_a_p = 0;
-                Float pv16[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { // (padding slots: row m, whose pi is +0.0, and P = +0.0)
-                    pv16[2 * u] = pi_s[c_rf[u].x];
-                    pv16[2 * u + 1] = pi_s[c_rf[u].z];
-                }
+                for (int qd = 0; qd < 4; ++qd)
+                    if (qd < nq) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const Float pp = u == off ? p_decayed : c_p[u];
-                    if (PM1) {
-                        const Float fa = (Float)((u & 1) ? c_rf[u >> 1].w : c_rf[u >> 1].y);
-                        sum_a_pi += fa * pv16[u];
-                        sum_a_p += fa * pp;
-                    } else {
-                        sum_a_pi += pv16[u];
-                        sum_a_p += pp;
+                        for (int u = 4 * qd; u < 4 * qd + 4; ++u)
+                            p_own_raw = u == off ? c_p[u] : p_own_raw;
                     }
-                }
+                p_decayed = p_own_raw * theta;
+                Float sum_a_pi = 0, sum_a_p = 0;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+                    if (qd < nq) { // (padding slots: row m, whose pi is +0.0, and P = +0.0)
+                        const uint4 iw = c_id[qd >> 1];
+                        const unsigned w0 = (qd & 1) ? iw.z : iw.x, w1 = (qd & 1) ? iw.w : iw.y;
+                        const unsigned h4[4] = { w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16 };
+                        Float pv4[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            pv4[t] = pi_s[h4[t] & 0x7fffu];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int u = 4 * qd + t;
+                            const Float pp = u == off ? p_decayed : c_p[u];
+                            if (PM1) {
+                                const Float fa = (h4[t] & 0x8000u) ? (Float)-1 : (Float)1;
+                                sum_a_pi += fa * pv4[t];
+                                sum_a_p += fa * pp;
+                            } else {
+                                sum_a_pi += pv4[t];
+                                sum_a_p += pp;
+                            }
+                        }
+                    }
                 for (int qb = c_desc.x + 16; qb < c_desc.x + c_desc.y; qb += 8) { // longer columns
                     Float p8[8], pi8[8];
                     int2 rf8[8];
@@ -349,6 +383,7 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
                     val += obj_amp * (PM1 ? c_cost : c_push);
                 key = order_key<Float>(val, maximize);
             }
+            BXH_PSTAMP(&prof, 3);
             // calculator_sort: the element's position = the number of keys below its own; two equal
             // keys collide on a position: the row counts again with the ids and flags the tie
             key_w[lane] = key; // (by element for now; lanes >= r: ~0)
@@ -431,7 +466,9 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
                 zflag[8 + wave] = sel;
             }
         }
+        BXH_PSTAMP(&prof, 4);
         __syncthreads(); // B1: every row of the group is sorted
+        BXH_PSTAMP(&prof, 5);
 
         // ---- what the reference does in sequence: shuffles and coins, row after row -----
         bool any_seq = false;
@@ -495,6 +532,7 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
             }
         }
 
+        BXH_PSTAMP(&prof, 6);
         // ---- affect (itm-common.hpp:382-467): pi_k and d, then every variable -------------
         if (mine) {
             const Float one = 1, two = 2;
@@ -527,7 +565,9 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
                 P[c_desc.z] = up ? p_decayed + d : p_decayed - d;
             }
         }
+        BXH_PSTAMP(&prof, 7);
         __syncthreads(); // B2: the group is done (P in memory, pi / x in LDS)
+        BXH_PSTAMP(&prof, 8);
         // R as the reference leaves it: the rows of the group wrote it in turn, so a position
         // keeps the value of the LAST row long enough to reach it
         if (mine) {
@@ -541,6 +581,7 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
         }
         it += g;
     }
+    BXH_PSTAMP(&prof, 9);
 
     __syncthreads();
     for (int i = tid; i < pb.m; i += T)
@@ -569,6 +610,11 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
         s.alg_bytes += alg_bytes;
         st.status[inst] = s;
     }
+#ifdef BXH_PROFILE
+    if (tid == 0)
+        for (int i = 0; i < 16; ++i)
+            st.prof[(size_t)inst * 32 + i] += prof.acc[i];
+#endif
 }
 
 } // namespace bxh
