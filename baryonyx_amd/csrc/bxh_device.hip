@@ -181,31 +181,79 @@ set_lds_limits(int device)
     BXH_SET_LDS(bxh::sweep_kernel_wide<float, false>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 1, 1>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 1, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 1, 3>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 1, 4>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 1>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 2>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 3>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 4>);
-    BXH_SET_LDS(bxh::sweep_kernel_wide<float, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 5>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 6>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 7>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 8>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 3, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 4, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 5, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 6, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 7, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, false, 4, 8, 2>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 1, 1>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 1, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 1, 3>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 1, 4>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 1>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 2>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 3>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 4>);
-    BXH_SET_LDS(bxh::sweep_kernel_wide<double, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 5>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 6>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 7>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 8>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 3, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 4, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 5, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 6, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 7, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<float, true, 4, 8, 2>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 1, 1>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 1, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 1, 3>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 1, 4>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 1>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 2>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 3>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 4>);
-    BXH_SET_LDS(bxh::sweep_kernel_wide<double, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 5>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 6>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 7>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 8>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 3, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 4, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 5, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 6, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 7, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, false, 4, 8, 2>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 1, 1>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 1, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 1, 3>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 1, 4>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 1>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 2>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 3>);
     BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 4>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 5>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 6>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 7>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 8>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 3, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 4, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 5, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 6, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 7, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_narrow<double, true, 4, 8, 2>);
+    BXH_SET_LDS(bxh::sweep_kernel_wide<float, true>);
+    BXH_SET_LDS(bxh::sweep_kernel_wide<double, false>);
+    BXH_SET_LDS(bxh::sweep_kernel_wide<double, true>);
 #undef BXH_SET_LDS
     if (device >= 0) {
         if (static_cast<size_t>(device) >= done.size())
@@ -236,8 +284,10 @@ struct bxh_handle_s
     int sw_chain = 0, sw_prod = 0; // v2: staging waves of the chain / a producer
     int romax = 0;             // longest per-owner part of a row
     int wide_g = 0;            // wide kernel (version 4): workgroups per instance
-    int narrow_w = 0, narrow_rpq = 0; // narrow kernel (version 5): waves per instance, staged row positions / 64
+    int narrow_w = 0, narrow_rph = 0; // narrow kernel (version 5): waves per instance, staged row positions / 32
+    bool narrow_occ2 = false;         // ... its 256-register build (two workgroups per CU)
     DevBuf<int4> ndesc;        // narrow kernel: per CSR element descriptors
+    DevBuf<int4> nrowc;        // narrow kernel: per row {first element, length | c_size << 16, bmin, bmax}
     bxh::NarrowParams npar{};
     bxh::NarrowRun nrun{};          // (max_sweeps == 0 outside bxh_run)
     DevBuf<int> run_out;            // [batch][4]
@@ -503,36 +553,45 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
         else
             BXH_LAUNCH((bxh::sweep_kernel_sw<Float, false>));
     } else if (h->version == 5) {
-#define BXH_NARROW(PM, WW, RQ)                                                 \
-    hipLaunchKernelGGL((bxh::sweep_kernel_narrow<Float, PM, WW, RQ>), dim3(h->batch), dim3(64 * WW), \
+#define BXH_NARROW_O(PM, WW, RQ, OC)                                           \
+    hipLaunchKernelGGL((bxh::sweep_kernel_narrow<Float, PM, WW, RQ, OC>), dim3(h->batch), dim3(64 * WW), \
                        h->lds_bytes, h->stream, h->dp, h->ds, a, h->npar, h->nrun)
-#define BXH_NARROW_W(PM, WW)                                                   \
+#define BXH_NARROW4(PM, RQ)                                                    \
     do {                                                                       \
-        if (h->narrow_rpq == 1)                                                \
-            BXH_NARROW(PM, WW, 1);                                             \
-        else if (h->narrow_rpq == 2)                                           \
-            BXH_NARROW(PM, WW, 2);                                             \
-        else if (h->narrow_rpq == 3)                                           \
-            BXH_NARROW(PM, WW, 3);                                             \
+        if (RQ >= 3 && h->narrow_occ2)                                         \
+            BXH_NARROW_O(PM, 4, (RQ >= 3 ? RQ : 3), 2);                        \
         else                                                                   \
-            BXH_NARROW(PM, WW, 4);                                             \
+            BXH_NARROW_O(PM, 4, RQ, 1);                                        \
     } while (0)
 #define BXH_NARROW_PM(PM)                                                      \
     do {                                                                       \
-        if (h->narrow_w == 4)                                                  \
-            BXH_NARROW_W(PM, 4);                                               \
-        else if (h->narrow_rpq == 1)                                           \
-            BXH_NARROW(PM, 1, 1);                                              \
-        else                                                                   \
-            BXH_NARROW(PM, 1, 2);                                              \
+        if (h->narrow_w == 4) {                                                \
+            switch (h->narrow_rph) {                                           \
+            case 1: BXH_NARROW4(PM, 1); break;                                 \
+            case 2: BXH_NARROW4(PM, 2); break;                                 \
+            case 3: BXH_NARROW4(PM, 3); break;                                 \
+            case 4: BXH_NARROW4(PM, 4); break;                                 \
+            case 5: BXH_NARROW4(PM, 5); break;                                 \
+            case 6: BXH_NARROW4(PM, 6); break;                                 \
+            case 7: BXH_NARROW4(PM, 7); break;                                 \
+            default: BXH_NARROW4(PM, 8); break;                                \
+            }                                                                  \
+        } else {                                                               \
+            switch (h->narrow_rph) {                                           \
+            case 1: BXH_NARROW_O(PM, 1, 1, 1); break;                          \
+            case 2: BXH_NARROW_O(PM, 1, 2, 1); break;                          \
+            case 3: BXH_NARROW_O(PM, 1, 3, 1); break;                          \
+            default: BXH_NARROW_O(PM, 1, 4, 1); break;                         \
+            }                                                                  \
+        }                                                                      \
     } while (0)
         if (pm1)
             BXH_NARROW_PM(true);
         else
             BXH_NARROW_PM(false);
-#undef BXH_NARROW_W
+#undef BXH_NARROW4
 #undef BXH_NARROW_PM
-#undef BXH_NARROW
+#undef BXH_NARROW_O
     } else if (h->version == 4) {
         if (pm1)
             hipLaunchKernelGGL((bxh::sweep_kernel_wide<Float, true>), dim3(h->batch * h->wide_g),
@@ -710,8 +769,8 @@ bxh_create(const bxh_problem* pb,
         const char* en = std::getenv("BXH_NARROW");
         const bool asked = en && en[0] == '1';
         const bool off = (en && en[0] == '0') || std::getenv("BXH_GROUPS") || (force_v1 && force_v1[0] == '1');
-        const int rpq = (rmax + 63) / 64;
-        const int nl = bxh::narrow_lds(m, n, h->nwords, rmax, float_type == BXH_FLOAT ? 4 : 8, rpq).total;
+        const int rph = (rmax + 31) / 32;
+        const int nl = bxh::narrow_lds(m, n, h->nwords, rmax, float_type == BXH_FLOAT ? 4 : 8, rph).total;
         narrow = !swave && !wide_g && !zsolver && pb->n_quad == 0 && rmax <= 256 && cmax <= 128 && m < 32767 &&
                  nl <= 160 * 1024 && !off && (asked || cmax <= 32);
     }
@@ -1181,15 +1240,26 @@ bxh_create(const bxh_problem* pb,
     if (narrow) {
         h->version = 5;
         h->threads = 64;
-        h->narrow_rpq = (rmax + 63) / 64;
+        h->narrow_rph = (rmax + 31) / 32;
         // four waves (one per SIMD of the CU) share a row of more than 64 elements;
         // BXH_NARROW_W=1 / 4 decides otherwise
         h->narrow_w = rmax > 64 ? 4 : 1;
         if (const char* ew = std::getenv("BXH_NARROW_W"))
-            h->narrow_w = (std::atoi(ew) == 4 || h->narrow_rpq > 2) ? 4 : 1; // (one wave: rows of up to 128)
+            h->narrow_w = (std::atoi(ew) == 4 || h->narrow_rph > 4) ? 4 : 1; // (one wave: rows of up to 128)
         h->threads = 64 * h->narrow_w;
         h->lds_bytes = static_cast<size_t>(
-          bxh::narrow_lds(m, n, h->nwords, rmax, static_cast<int>(h->fsize), h->narrow_rpq).total);
+          bxh::narrow_lds(m, n, h->nwords, rmax, static_cast<int>(h->fsize), h->narrow_rph).total);
+        // more instances than CUs, and two LDS plans fit a CU: the 256-register build, two
+        // workgroups per CU (BXH_NARROW_OCC=1 / 2 decides otherwise)
+        {
+            int cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+            h->narrow_occ2 = h->narrow_w == 4 && h->narrow_rph >= 3 && batch > cus && 2 * h->lds_bytes <= 160 * 1024;
+            if (const char* eo = std::getenv("BXH_NARROW_OCC"))
+                h->narrow_occ2 = h->narrow_w == 4 && h->narrow_rph >= 3 && eo[0] == '2';
+        }
     }
     if (std::getenv("BXH_DEBUG"))
         std::fprintf(stderr, "bxh: kernel v%d threads=%d lds=%zu np=%d groups=%d pipe=%d (chain %d, producer %d staging waves, lookahead %d)\n",
@@ -1405,6 +1475,12 @@ bxh_create(const bxh_problem* pb,
             }
             HIP_TRY(h->ndesc.upload(nd));
             h->npar.desc = h->ndesc.p;
+            std::vector<int4> rc(static_cast<size_t>(m));
+            for (int k = 0; k != m; ++k)
+                rc[k] = make_int4(pb->row_ptr[k], (pb->row_ptr[k + 1] - pb->row_ptr[k]) | ((pm1 ? bneg[k] : 0) << 16),
+                                  bmin[k], bmax[k]);
+            HIP_TRY(h->nrowc.upload(rc));
+            h->npar.rowc = h->nrowc.p;
         }
     }
     h->h_row_pos = std::move(row_pos);

@@ -45,7 +45,11 @@ struct NarrowParams
     const int4* desc; // [nnz][2] per CSR element: {first CSC slot of its column, real entries of
                       //  the column, CSC slot of the element, column (bit 31: coefficient -1)},
                       //  {cost of the column as Float bits, 0, 0}
+    const int4* rowc; // [m] per row: {first element, length | c_size << 16, bmin, bmax} (the bounds as
+                      //  the Solver constructors clamp them)
 };
+
+constexpr int NARROW_RING = 8; // rows of the list whose constants wait in LDS (fetched four rows ahead)
 
 // Several sweeps of solver_functor's loop (itm-solver-common.hpp:135-213) in one
 // launch: after every sweep the instance's kappa moves as the host would move
@@ -68,21 +72,21 @@ struct NarrowLds
 {
     int off_pi, off_x, off_xbest, off_rows, off_rowc, off_slot, off_desc, off_cols, off_val, off_key, off_id,
       off_tab, off_rank, off_stale, off_misc, off_part, total, n2;
-    int rp;        // row positions staged (64 * RPQ)
+    int rp;        // row positions staged (32 * RPH)
     int desc_size; // bytes of one descriptor buffer
     int cols_size; // bytes of one column buffer (P lines, then row ids)
     int ids_off;   // offset of the row ids inside a column buffer
 };
 
-// rpq: staged row positions / 64 (rmax <= 64 * rpq)
+// rph: staged row positions / 32 (rmax <= 32 * rph): whole load instructions' worth of the longest row
 __host__ __device__ inline NarrowLds
-narrow_lds(int m, int n, int nwords, int rmax, int fsize, int rpq)
+narrow_lds(int m, int n, int nwords, int rmax, int fsize, int rph)
 {
     auto al = [](int v) { return (v + 15) & ~15; };
     NarrowLds p;
     const int n2 = next_pow2(rmax < 2 ? 2 : rmax);
     p.n2 = n2;
-    p.rp = 64 * rpq;
+    p.rp = 32 * rph;
     p.desc_size = p.rp * 32;
     p.ids_off = p.rp * 16 * fsize;
     p.cols_size = p.ids_off + p.rp * 32;
@@ -91,12 +95,11 @@ narrow_lds(int m, int n, int nwords, int rmax, int fsize, int rpq)
     o = al(o + (m + 1) * fsize);
     p.off_x = o;
     o = al(o + nwords * 8);
-    p.off_xbest = o; // (several sweeps per launch) x behind the best sweep so far
-    o = al(o + nwords * 8);
+    p.off_xbest = o; // (unused: x behind the best sweep so far goes to NarrowRun::xbest directly)
     p.off_rows = o;
     o = al(o + m * 4);
-    p.off_rowc = o; // {first element, length | c_size << 16, bmin, bmax} of every row of the list
-    o = al(o + m * 16);
+    p.off_rowc = o; // {first element, length | c_size << 16, bmin, bmax} of the next rows of the list
+    o = al(o + NARROW_RING * 16);
     p.off_slot = o; // per column: slot (inside the column) of its entry in the row that wrote it last
     o = al(o + n);
     p.off_desc = o; // 3 descriptor buffers (rows it, it+1, it+2)
@@ -220,11 +223,14 @@ typedef unsigned narrow_v4u __attribute__((ext_vector_type(4)));
 // (itm-solver-inequalities-01.cpp:208-296, -equalities-01.cpp:184-270,
 //  -equalities-101.cpp:208-307, -inequalities-101.cpp:250-347).  W waves per
 // instance (1: no barrier does anything; 4: one wave per SIMD of the CU, two
-// barriers per row), RPQ * 64 staged row positions (rmax <= 64 * RPQ).  The
+// barriers per row), RPH * 32 staged row positions (rmax <= 32 * RPH).  The
 // first 16-entry piece of every column is staged ahead; longer columns fetch
 // the rest on demand.
-template<typename Float, bool PM1, int W, int RPQ>
-__global__ __launch_bounds__(64 * W) void
+// OCC = 2 (W = 4): at most 256 registers, so that two workgroups -- one wave each per SIMD -- share
+// a CU where their LDS plans allow it; the launch takes that build when the batch exceeds the CUs
+// (the registers it gives up cost the lone workgroup of a CU an eighth of its speed).
+template<typename Float, bool PM1, int W, int RPH, int OCC = 1>
+__global__ __launch_bounds__(64 * W, OCC) void
 sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, NarrowRun run)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -238,14 +244,13 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, Nar
     constexpr int CH = PB / 16;      // its 16-byte chunks (8 / 4)
     constexpr int EPC = 16 / FS;     // values per chunk (2 / 4)
     constexpr int CPI = 64 / CH;     // columns one load instruction covers (8 / 16)
-    constexpr int RP = 64 * RPQ;     // row positions
+    constexpr int RP = 32 * RPH;     // row positions
     constexpr int NE = (RP + T - 1) / T; // row elements per thread
     constexpr int NIP = RP / CPI, NII = RP / 32, NID = RP / 32; // load instructions of a row
     constexpr int NIPW = (NIP + W - 1) / W, NIIW = (NII + W - 1) / W; // ... of one wave
-    const NarrowLds L = narrow_lds(pb.m, pb.n, pb.nwords, pb.rmax, FS, RPQ);
+    const NarrowLds L = narrow_lds(pb.m, pb.n, pb.nwords, pb.rmax, FS, RPH);
     Float* pi_s = (Float*)(smem + L.off_pi);
     unsigned* x_s = (unsigned*)(smem + L.off_x);
-    unsigned* xbest_s = (unsigned*)(smem + L.off_xbest);
     int* rows_s = (int*)(smem + L.off_rows);
     int4* rowc_s = (int4*)(smem + L.off_rowc);
     unsigned char* slot_s = smem + L.off_slot;
@@ -346,19 +351,17 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, Nar
         rng.s = (unsigned)misc_s[MS_RNG];
     }
 
-    // The constants of every row of the list, in sweep order, fetched by all
-    // threads at once (the row loop then reads them from LDS: no memory round trip
-    // per row), and the algorithmic bytes of the sweep (every row of the list is
-    // updated exactly once; the figures are whole numbers, any order adds up the same).
+    // The constants of the first rows of the list, in sweep order (a ring in LDS: the row
+    // loop fetches those of row it + 4 while it works on row it -- no memory round trip per
+    // row), and the algorithmic bytes of the sweep (every row of the list is updated
+    // exactly once; the figures are whole numbers, any order adds up the same).
     double alg_bytes = 0.0; // thread 0
     {
         double bytes = 0.0;
         for (int i = tid; i < nrows; i += T) {
             const int k = (ord == 1) ? rows_s[nrows - 1 - i] : rows_s[i];
-            const int rs = pb.row_ptr[k];
-            const int r = pb.row_ptr[k + 1] - rs;
-            const int cs = PM1 ? pb.bneg[k] : 0;
-            rowc_s[i] = make_int4(rs, r | (cs << 16), pb.bmin[k], pb.bmax[k]);
+            if (i < NARROW_RING / 2) // (the row loop fetches the others, four rows ahead)
+                rowc_s[i] = np.rowc[k];
             bytes += pb.row_bytes[k];
         }
 #pragma unroll
@@ -379,7 +382,7 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, Nar
     auto issue_desc = [&](int it) {
         if (it >= nrows)
             return;
-        const int4 c = rowc_s[it];
+        const int4 c = rowc_s[it & (NARROW_RING - 1)];
         const int rs = __builtin_amdgcn_readfirstlane(c.x);
         const int r = __builtin_amdgcn_readfirstlane(c.y & 0xffff);
         const unsigned dst = lds0 + (unsigned)L.off_desc + (unsigned)(it % 3) * (unsigned)L.desc_size;
@@ -404,7 +407,7 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, Nar
     auto issue_cols = [&](int it) {
         if (it >= nrows)
             return;
-        const int r = __builtin_amdgcn_readfirstlane(rowc_s[it].y & 0xffff);
+        const int r = __builtin_amdgcn_readfirstlane(rowc_s[it & (NARROW_RING - 1)].y & 0xffff);
         const int4* dsc = (const int4*)(smem + L.off_desc + (it % 3) * L.desc_size);
         int qp[NIPW], qi[NIIW];
 #pragma unroll
@@ -463,11 +466,21 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, Nar
 
     for (int it = 0; it < nrows; ++it) {
         // ---- the loads of the rows ahead (complete at this row's wait_loads) -----
+        // the constants of row it + 4 first (one lane of the last wave; into the ring behind this
+        // row's wait for its loads).  In FRONT of the column loads: the compiler waits for a
+        // register's older load before it writes the register again, and its wait counter is
+        // in order -- behind them that wait would be for the columns just asked for
+        int4 rc_ahead = make_int4(0, 0, 0, 0);
+        const bool rc_mine = tid == T - 64 && it + NARROW_RING / 2 < nrows;
+        if (rc_mine) {
+            const int ia = it + NARROW_RING / 2;
+            rc_ahead = np.rowc[(ord == 1) ? rows_s[nrows - 1 - ia] : rows_s[ia]];
+        }
         issue_desc(it + 2);
         issue_cols(it + 1);
         BXH_PSTAMP(&prof, 1);
 
-        const int4 rowc = rowc_s[it];
+        const int4 rowc = rowc_s[it & (NARROW_RING - 1)];
         const int k = __builtin_amdgcn_readfirstlane(
           (ord == 1) ? rows_s[nrows - 1 - it] : rows_s[it]);
         const int r = __builtin_amdgcn_readfirstlane(rowc.y & 0xffff);
@@ -805,6 +818,8 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, Nar
         // the columns read ahead must have arrived before this row's stores to
         // the same lines are issued
         wait_loads();
+        if (rc_mine)
+            rowc_s[(it + NARROW_RING / 2) & (NARROW_RING - 1)] = rc_ahead;
         BXH_PSTAMP(&prof, 4);
         // the tie filter of the next row lives where this row's lines were read from
         if (tid < 64)
@@ -1083,8 +1098,8 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, Nar
             if (cnt < best_rem) {
                 best_rem = cnt;
                 best_i = i;
-                for (int w = tid; w < 2 * pb.nwords; w += T)
-                    xbest_s[w] = x_s[w];
+                for (int w = tid; w < 2 * pb.nwords; w += T) // (global memory: read by the host only)
+                    run.xbest[(size_t)inst * (2 * pb.nwords) + w] = x_s[w];
             }
             if (i > run.w_limit)
                 kappa = kappa + (Float)run.kappa_inc[cnt];
@@ -1107,9 +1122,6 @@ sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, Nar
     for (int i = tid; i <= pb.rmax; i += T)
         staleg[i] = stale_s[i];
     if (run.max_sweeps > 0) {
-        if (best_rem != 0x7fffffff)
-            for (int i = tid; i < 2 * pb.nwords; i += T)
-                run.xbest[(size_t)inst * (2 * pb.nwords) + i] = xbest_s[i];
         if (tid == 0) {
             run.out[inst * 4 + 0] = sweeps_done;
             run.out[inst * 4 + 1] = best_rem;

@@ -113,6 +113,34 @@ def test_narrow_baseline_shapes_many_instances(oracle, bxh, name, monkeypatch):
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=70, sweeps=4, push_at=(2,), expect_form=5)
 
 
+@pytest.mark.parametrize("name", ["aa04", "ne4-pm1-max", "ne2-npc2-scp"])
+def test_narrow_two_workgroups_per_cu_build(oracle, bxh, name, monkeypatch):
+    """The 256-register build of the four-wave kernel (what bxh_create launches when the batch
+    exceeds the CUs and two LDS plans fit one: two workgroups per CU), forced onto small batches,
+    and once by itself with more instances than CUs."""
+    monkeypatch.setenv("BXH_NARROW_W", "4")
+    monkeypatch.setenv("BXH_NARROW_OCC", "2")
+    if name == "aa04":
+        run_case(oracle, bxh, synth.config_c3("int"), 1, False, 0, 0.0, batch=5, sweeps=5, push_at=(2,),
+                 expect_form=5)
+        monkeypatch.delenv("BXH_NARROW_OCC")
+        monkeypatch.delenv("BXH_NARROW_W")
+        monkeypatch.delenv("BXH_NARROW", raising=False)
+        run_case(oracle, bxh, synth.config_c3("real"), 1, False, 0, 0.0, batch=300, sweeps=2, expect_form=5)
+    else:
+        _, maker, float_type, maximize, order, x0p = [c for c in SHAPES if c[0] == name][0]
+        run_case(oracle, bxh, maker(), float_type, maximize, order, x0p, batch=3, sweeps=8, push_at=(3, 6),
+                 expect_form=5)
+
+
+def test_narrow_lists_shorter_than_the_row_ring(oracle, bxh):
+    """The constants of a row wait in a ring of eight, fetched four rows ahead: lists of 1 .. 9
+    rows (the violated rows of later sweeps) end inside the ring's first round."""
+    for m in (1, 2, 3, 4, 5, 8, 9):
+        inst = synth.make_scp(m, 120, 0.3, "real", 400 + m)
+        run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=4, push_at=(2,), expect_form=5)
+
+
 RUN_CASES = [
     ("scp-real", lambda: synth.make_scp(60, 400, 0.06, "real", 311), 1, 1, 0),
     ("spp-int-f32-reversing", lambda: synth.make_spp(40, 300, 0.06, "int", 312), 0, 0, 1),

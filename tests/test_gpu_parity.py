@@ -57,7 +57,7 @@ def run_case(oracle, bxh, inst, float_type, maximize, order, x0p, batch=3, sweep
         if order != 7:  # pi_sign_change walks iota(n); remaining counts the violated rows
             assert rem[b] == len(s.violated())
 
-    kappa = np.array([0.0 + 0.01 * b for b in range(batch)])
+    kappa = np.array([0.0 + 0.01 * (b % 64) for b in range(batch)])  # (kappa < 1)
     for it in range(sweeps):
         push = it in push_at
         amp = 5.0 if push else 0.0
