@@ -2338,8 +2338,9 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 }
                 __syncthreads();
             }
-            const int g = __builtin_amdgcn_readfirstlane(t_b[it - tbase].z);
-            if (g > 0) {
+            int g = __builtin_amdgcn_readfirstlane(t_b[it - tbase].z);
+            bool z_again = false; // the outer loop's top has to look at position `it` (end of the list, table refill)
+            while (g > 0) { // group after group: the general path's state is not touched in here
                 BXH_STAMP(8);
                 const int s0 = it - tbase;
                 const bool mine = wave < g;
@@ -2711,7 +2712,15 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 }
                 if (mine)
                     alg_w += t_rb[sl]; // (lane 0 of the wave counts; summed at the end)
-                it += g - 1;
+                it += g;
+                if (it >= nrows || (it + 2 * NW > tbase + ZW_TABLE && tbase + ZW_TABLE < nrows)) {
+                    z_again = true;
+                    break;
+                }
+                g = __builtin_amdgcn_readfirstlane(t_b[it - tbase].z);
+            }
+            if (z_again) {
+                --it;
                 continue;
             }
             // the general path for this row (the table holds its scalars)
