@@ -389,13 +389,14 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
             key_w[lane] = key; // (by element for now; lanes >= r: ~0)
             __builtin_amdgcn_wave_barrier();
             const int r8 = (r + 7) & ~7;
-            for (int j0 = 0; j0 < r8; j0 += 8) {
-                ulonglong2 q[4];
+            // (sixteen keys per round trip: the lanes from r on hold the largest key, which counts nowhere)
+            for (int j0 = 0; j0 < r8; j0 += 16) {
+                ulonglong2 q[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 8; ++u)
                     q[u] = reinterpret_cast<const ulonglong2*>(key_w + j0)[u];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     rank += q[u].x < key;
                     rank += q[u].y < key;
                 }
