@@ -549,9 +549,11 @@ launch_sweep(bxh_handle h, const bxh::DevSweep& a)
             BXH_LAUNCH((bxh::sweep_kernel_z<Float, false>));
     } else if (h->version == 7) {
         if (pm1)
-            BXH_LAUNCH((bxh::sweep_kernel_sw<Float, true>));
+            hipLaunchKernelGGL((bxh::sweep_kernel_sw<Float, true>), dim3(h->batch), dim3(h->threads), h->lds_bytes,
+                               h->stream, h->dp, h->ds, a, h->nrun);
         else
-            BXH_LAUNCH((bxh::sweep_kernel_sw<Float, false>));
+            hipLaunchKernelGGL((bxh::sweep_kernel_sw<Float, false>), dim3(h->batch), dim3(h->threads), h->lds_bytes,
+                               h->stream, h->dp, h->ds, a, h->nrun);
     } else if (h->version == 5) {
 #define BXH_NARROW_O(PM, WW, RQ, OC)                                           \
     hipLaunchKernelGGL((bxh::sweep_kernel_narrow<Float, PM, WW, RQ, OC>), dim3(h->batch), dim3(64 * WW), \
@@ -2755,7 +2757,7 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
 int
 bxh_run_supported(bxh_handle h)
 {
-    return (h && h->version == 5) ? 1 : 0;
+    return (h && (h->version == 5 || h->version == 7)) ? 1 : 0;
 }
 
 int
@@ -2763,8 +2765,8 @@ bxh_run(bxh_handle h, const bxh_run_args* a, bxh_status* status_out, bxh_run_sta
 {
     if (!h || !a || !a->kappa || !a->kappa_inc)
         return fail(BXH_ERR_INVALID, "null argument");
-    if (h->version != 5)
-        return fail(BXH_ERR_UNSUPPORTED, "bxh_run: only the short-row kernel runs several sweeps per launch");
+    if (h->version != 5 && h->version != 7)
+        return fail(BXH_ERR_UNSUPPORTED, "bxh_run: only the short-row kernels run several sweeps per launch");
     if (a->order > BXH_ORDER_RANDOM_SORTING)
         return fail(BXH_ERR_UNSUPPORTED, "bxh_run: row orders none / reversing / random_sorting only");
     if (a->max_sweeps <= 0)

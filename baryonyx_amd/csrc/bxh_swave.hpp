@@ -17,6 +17,7 @@
 #define BXH_SWAVE_HPP
 
 #include "bxh_kernels.hpp"
+#include "bxh_narrow.hpp" // NarrowRun: several sweeps of solver_functor's loop per launch (bxh_run)
 
 namespace bxh {
 
@@ -53,7 +54,7 @@ sw_lds(int m, int nwords, int rmax, int fsize)
 
 template<typename Float, bool PM1>
 __global__ __launch_bounds__(256) void
-sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
+sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a, NarrowRun run)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int inst = blockIdx.x;
@@ -87,7 +88,7 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
     int* const out_list = keep ? st.slist + (size_t)inst * st.lcap : st.vlist + (size_t)inst * st.lcap;
     const Float* const cost = (const Float*)pb.cost;
 
-    const Float kappa = (Float)a.kappa[inst];
+    Float kappa = (Float)a.kappa[inst]; // (moves behind a sweep of a multi-sweep launch, bxh_run)
     const Float delta = (Float)a.delta;
     const Float theta = (Float)a.theta;
     const Float obj_amp = (Float)a.obj_amp;
@@ -109,8 +110,17 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
         prof.acc[i] = 0;
     prof.t = wall_clock64();
 #endif
-    const int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
+    int nrows = use_m ? st.mcount[inst] : st.vcount[inst];
     double alg_w = 0.0; // algorithmic bytes of the rows this wave took (lane 0 counts)
+    // Several sweeps of solver_functor's loop (itm-solver-common.hpp:135-213) in one launch, as in
+    // the short-row kernel (bxh_narrow.hpp: NarrowRun): behind every sweep kappa moves as the host
+    // would move it, the launch ends when no row is violated, when kappa passes kappa_max or after
+    // max_sweeps; pi / x / R's leftovers stay in LDS in between, the row list is the one the sweep
+    // left in memory.  run.max_sweeps == 0: one sweep, nothing of this (bxh_sweep).
+    int cnt = 0, sweeps_done = 0, stop_why = 0, best_rem = 0x7fffffff, best_i = 0;
+    unsigned long long rows_total = 0;
+    unsigned rows_last = 0;
+    for (int sw = 0;; ++sw) {
 
     if (tid == 0) {
         pi_s[pb.m] = 0;
@@ -585,14 +595,50 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
     BXH_PSTAMP(&prof, 9);
 
     __syncthreads();
+    cnt = rebuild_violated(pb, x_s, st.vflag + (size_t)inst * pb.m, out_list, misc_s + MS_WAVES + 16);
+    // ---- solver_functor's bookkeeping behind a sweep (every thread alike) ------------
+    rows_total += (unsigned long long)nrows;
+    rows_last = (unsigned)nrows;
+    sweeps_done = sw + 1;
+    if (run.max_sweeps <= 0)
+        break;
+    {
+        const int i = run.first_i + sw;
+        if (cnt == 0)
+            stop_why = 1;
+        else {
+            if (cnt < best_rem) {
+                best_rem = cnt;
+                best_i = i;
+                for (int w = tid; w < 2 * pb.nwords; w += T) // (global memory: read by the host only)
+                    run.xbest[(size_t)inst * (2 * pb.nwords) + w] = x_s[w];
+            }
+            if (i > run.w_limit)
+                kappa = kappa + (Float)run.kappa_inc[cnt];
+            if (kappa > (Float)run.kappa_max)
+                stop_why = 2;
+        }
+        if (stop_why || sw + 1 >= run.max_sweeps)
+            break;
+    }
+    nrows = cnt; // (out_list == vlist in the orders a multi-sweep launch takes: the next sweep's list)
+    __syncthreads();
+    } // sweeps of this launch
+
+    __syncthreads();
     for (int i = tid; i < pb.m; i += T)
         pig[i] = pi_s[i];
     for (int i = tid; i < 2 * pb.nwords; i += T)
         xg[i] = x_s[i];
     for (int i = tid; i <= pb.rmax; i += T)
         staleg[i] = stale_s[i];
-
-    const int cnt = rebuild_violated(pb, x_s, st.vflag + (size_t)inst * pb.m, out_list, misc_s + MS_WAVES + 16);
+    if (run.max_sweeps > 0 && tid == 0) {
+        run.out[inst * 4 + 0] = sweeps_done;
+        run.out[inst * 4 + 1] = best_rem;
+        run.out[inst * 4 + 2] = best_i;
+        run.out[inst * 4 + 3] = stop_why;
+        run.kappa_out[inst] = (double)kappa;
+    }
     if (lane == 0)
         t_rb[wave] = alg_w;
     __syncthreads();
@@ -606,8 +652,8 @@ sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a)
         s.remaining = cnt;
         s.pi_changed = misc_s[MS_PICH];
         s.rng = rng.s;
-        s.rows_in_sweep = (unsigned)nrows;
-        s.row_updates += (unsigned long long)nrows;
+        s.rows_in_sweep = rows_last;
+        s.row_updates += rows_total;
         s.alg_bytes += alg_bytes;
         st.status[inst] = s;
     }

@@ -958,9 +958,30 @@ solve_problem(const context& ctx, const problem& pb)
                     break;
                 if (many && p.pushing_iteration_limit > 0) {
                     // the iterations behind a push sweep: the same loop, on the device
+                    // (the first sweeps one launch each: most of these loops end after one or two
+                    // sweeps, and a multi-sweep launch costs three transfers more than a sweep)
                     bool out_of_time = false;
                     int iter = 0;
-                    while (iter < p.pushing_iteration_limit) {
+                    bool ended = false;
+                    for (; iter < std::min(p.pushing_iteration_limit, 3); ++iter) {
+                        slv.kappa[0] = static_cast<double>(kappa);
+                        slv.sweep(static_cast<double>(delta), static_cast<double>(theta), false, 0.0, order);
+                        remaining = slv.status[0].remaining;
+                        if (remaining == 0) {
+                            store_value(-push * p.pushing_iteration_limit - iter - 1);
+                            ended = true;
+                            break;
+                        }
+                        if (iter > p.w)
+                            kappa += kappa_step * std::pow(static_cast<Float>(remaining) /
+                                                             static_cast<Float>(slv.m),
+                                                           alpha);
+                        if (kappa > kappa_max || timeout()) {
+                            ended = true;
+                            break;
+                        }
+                    }
+                    while (!ended && iter < p.pushing_iteration_limit) {
                         const int chunk = std::min(p.pushing_iteration_limit - iter, 256);
                         slv.kappa[0] = static_cast<double>(kappa);
                         const bxh_run_status rs = slv.run(static_cast<double>(delta), static_cast<double>(theta),

@@ -178,7 +178,7 @@ int bxh_rmax(bxh_handle h);
 int bxh_kernel_form(bxh_handle h);
 /* Several sweeps of solver_functor's main loop (lib/src/itm-solver-common.hpp:
  * 135-213) in ONE launch, for the handles bxh_run_supported() says yes to (the
- * short-row kernel) and the row orders none / reversing / random_sorting:
+ * short-row kernels, forms 5 and 7) and the row orders none / reversing / random_sorting:
  *   for (i = first_i; ; ++i) { remaining = compute.run(kappa);
  *       if (remaining == 0) stop (1);
  *       if (remaining < best) { best = remaining; keep x; }

@@ -150,6 +150,10 @@ RUN_CASES = [
 
 @pytest.mark.parametrize("case", RUN_CASES, ids=[c[0] for c in RUN_CASES])
 def test_run_of_many_sweeps_equals_single_sweeps(oracle, bxh, case):
+    run_equals_single_sweeps(oracle, bxh, case, 5)
+
+
+def run_equals_single_sweeps(oracle, bxh, case, form):
     """bxh_run -- solver_functor's loop (itm-solver-common.hpp:135-213) with up to
     `max_sweeps` sweeps per launch, kappa moved on the device by the host's own
     increments -- against the same loop driven sweep by sweep (one launch each,
@@ -167,7 +171,7 @@ def test_run_of_many_sweeps_equals_single_sweeps(oracle, bxh, case):
 
     def fresh():
         d = bxh.DeviceBatch(inst, cost, batch, float_type=float_type)
-        assert d.kernel_form == 5
+        assert d.kernel_form == form, d.kernel_form
         for b in range(batch):
             d.set_x(b, random_x(inst.n, 0.02 * b, 90 + b))
             d.set_rng(b, 1000 + b)

@@ -123,3 +123,16 @@ def sat_like(seed):
 def test_swave_sat_like_rows(oracle, bxh, order):
     run_case(oracle, bxh, sat_like(700 + order), 1, False, order, 0.5, batch=2, sweeps=8, push_at=(),
              expect_form=7)
+
+
+def test_swave_run_of_many_sweeps_equals_single_sweeps(oracle, bxh):
+    """bxh_run on the wave-per-row form: launches of up to seven sweeps of solver_functor's
+    loop (kappa moved on the device, the row list of a sweep read by the next) against the same
+    loop driven sweep by sweep -- sweeps, stop, kappa, x, pi, P, engine and the x of the best sweep."""
+    from test_gpu_narrow import RUN_CASES, run_equals_single_sweeps
+
+    for case in RUN_CASES:
+        assert _fits(case[1]())
+        run_equals_single_sweeps(oracle, bxh, case, 7)
+    # a list of several tables (more than 64 rows violated at the start), random row order
+    run_equals_single_sweeps(oracle, bxh, ("scp-200", lambda: synth.make_scp(200, 1000, 0.02, "int", 41), 1, 1, 2), 7)
