@@ -290,8 +290,9 @@ struct bxh_handle_s
     DevBuf<int4> nrowc;        // narrow kernel: per row {first element, length | c_size << 16, bmin, bmax}
     bxh::NarrowParams npar{};
     bxh::NarrowRun nrun{};          // (max_sweeps == 0 outside bxh_run)
-    DevBuf<int> run_out;            // [batch][4]
-    DevBuf<double> run_kappa, run_inc; // [batch], [m + 1]
+    DevBuf<double> run_out;         // [batch][2] the four ints of a launch's outcome, then [batch] kappa: one transfer
+    DevBuf<double> run_inc;         // [m + 1]
+    std::vector<double> run_inc_host; // ... as uploaded last (the table of a solve does not change)
     DevBuf<unsigned> run_xbest;     // [batch][2 * nwords]
     bool device_built = false; // bxh_create_device: no host copy of the matrix exists
     // 1: the instance's list R is known to be empty (a sweep over it is a no-op);
@@ -2774,21 +2775,25 @@ bxh_run(bxh_handle h, const bxh_run_args* a, bxh_status* status_out, bxh_run_sta
     HIP_TRY(hipSetDevice(h->device));
     const size_t B = static_cast<size_t>(h->batch);
     if (!h->run_out.p) {
-        HIP_TRY(h->run_out.alloc(B * 4));
-        HIP_TRY(h->run_kappa.alloc(B));
+        HIP_TRY(h->run_out.alloc(B * 3));
         HIP_TRY(h->run_inc.alloc(static_cast<size_t>(h->m) + 1));
         HIP_TRY(h->run_xbest.alloc(B * 2 * h->nwords));
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(h->run_inc.p, a->kappa_inc, (static_cast<size_t>(h->m) + 1) * sizeof(double),
-                      hipMemcpyHostToDevice));
+    {
+        const size_t ni = static_cast<size_t>(h->m) + 1;
+        if (h->run_inc_host.size() != ni || std::memcmp(h->run_inc_host.data(), a->kappa_inc, ni * sizeof(double)) != 0) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipMemcpy(h->run_inc.p, a->kappa_inc, ni * sizeof(double), hipMemcpyHostToDevice));
+            h->run_inc_host.assign(a->kappa_inc, a->kappa_inc + ni);
+        }
+    }
     h->nrun.max_sweeps = a->max_sweeps;
     h->nrun.first_i = a->first_i;
     h->nrun.w_limit = a->w_limit;
     h->nrun.kappa_max = a->kappa_max;
     h->nrun.kappa_inc = h->run_inc.p;
-    h->nrun.out = h->run_out.p;
-    h->nrun.kappa_out = h->run_kappa.p;
+    h->nrun.out = reinterpret_cast<int*>(h->run_out.p);
+    h->nrun.kappa_out = h->run_out.p + 2 * B;
     h->nrun.xbest = h->run_xbest.p;
     bxh_sweep_args sa{};
     sa.kappa = a->kappa;
@@ -2808,10 +2813,10 @@ bxh_run(bxh_handle h, const bxh_run_args* a, bxh_status* status_out, bxh_run_sta
     if (int rc2 = bxh_status_sync(h, status_out))
         return rc2;
     if (run_out) {
-        std::vector<int> ro(B * 4);
-        std::vector<double> ko(B);
-        HIP_TRY(hipMemcpy(ro.data(), h->run_out.p, B * 4 * sizeof(int), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ko.data(), h->run_kappa.p, B * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> blob(B * 3);
+        HIP_TRY(hipMemcpy(blob.data(), h->run_out.p, B * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        const int* ro = reinterpret_cast<const int*>(blob.data());
+        const double* ko = blob.data() + 2 * B;
         for (size_t b = 0; b != B; ++b) {
             run_out[b].sweeps = ro[b * 4];
             run_out[b].best_remaining = ro[b * 4 + 1];
