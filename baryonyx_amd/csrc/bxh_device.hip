@@ -351,6 +351,7 @@ struct bxh_handle_s
     DevBuf<unsigned long long> zconf; // Z kernel: rows k + 1 .. k + 64 that share a column with row k
     DevBuf<int4> zdesc;               // Z kernel, wave form: two 16-byte records per CSR element
     DevBuf<int2> zcolrf;              // Z kernel, wave form: {row, |coefficient|} of every padded CSC slot
+    DevBuf<unsigned> zcolp;           // ... packed: row | |coefficient| << 16
     int zwave = 0;                    // Z kernel: rows of up to 63 elements go wave per row (groups)
     int swave = 0;                    // 01 / 101 solvers, every row of 1 .. 63 elements: a wave per row (version 7)
     DevBuf<unsigned char> zscratch;
@@ -1169,6 +1170,9 @@ bxh_create(const bxh_problem* pb,
             if (h->zwave &&
                 bxh::lds_bytes_z(m, h->nwords, rmax, static_cast<int>(h->fsize), true) > lds_limit)
                 h->zwave = 0;
+            // (the wave form reads a slot's row and |coefficient| as one 32-bit word)
+            if (h->zwave && (m > 65535 || *std::max_element(col_fac.begin(), col_fac.end()) > 65535))
+                h->zwave = 0;
         }
         const int zl = bxh::lds_bytes_z(m, h->nwords, rmax, static_cast<int>(h->fsize), h->zwave != 0);
         if (zl > lds_limit)
@@ -1438,6 +1442,12 @@ bxh_create(const bxh_problem* pb,
             }
         }
         HIP_TRY(h->zcolrf.upload(rf));
+        if (zsolver) { // (bxh_create took the wave form only where both halves fit 16 bits)
+            std::vector<unsigned> rp(static_cast<size_t>(nnzp));
+            for (size_t q = 0; q != static_cast<size_t>(nnzp); ++q)
+                rp[q] = (static_cast<unsigned>(col_row[q]) & 0xffffu) | (static_cast<unsigned>(col_fac[q]) << 16);
+            HIP_TRY(h->zcolp.upload(rp));
+        }
     }
     {
         std::vector<unsigned char> c;
@@ -1701,6 +1711,7 @@ bxh_create(const bxh_problem* pb,
     dp.zconf = h->zconf.p;
     dp.zdesc = h->zdesc.p;
     dp.zcolrf = h->zcolrf.p;
+    dp.zcolp = h->zcolp.p;
     dp.zwave = h->zwave;
     dp.bmin = h->bmin.p;
     dp.bmax = h->bmax.p;

@@ -77,6 +77,7 @@ struct DevProblem
     const int4* zdesc;         // [2 nnz] wave form: {first slot, padded length, own slot, column},
                                //         {coefficient, cost bits (lo, hi), real entries of the column} of CSR element e
     const int2* zcolrf;        // [nnzp]  wave form: {row, |coefficient|} of CSC slot q
+    const unsigned* zcolp;     // [nnzp]  Z kernel, wave form: row | |coefficient| << 16 (m and |a| below 65536)
     const int* bmin;           // [m] clamped as the Solver constructor does
     const int* bmax;           // [m]
     const int* bneg;           // [m] negative_factor (== c_size of the row)
@@ -2365,7 +2366,7 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 // writes is in this column -- the pi of the slots' rows, read from LDS ONCE;
                 // the repair pass only swaps in the row's own slot (new pi_k, new P).
                 Float c_p[16], c_f[16], c_pi[16];
-                int4 c_rf[8]; // {row, |a|} of two slots each, as loaded
+                uint4 c_rp[4]; // row | |a| << 16 of four slots each, as loaded
                 int4 c_desc = make_int4(0, 0, 0, 0);
                 Float c_cost = 0, p_own_raw = 0;
                 int fe = 0;
@@ -2405,10 +2406,10 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                             c_p[4 * u + 3] = (Float)t4.w;
                         }
                     }
-                    const int4* rfv = reinterpret_cast<const int4*>(pb.zcolrf + cs.x);
+                    const uint4* rfv = reinterpret_cast<const uint4*>(pb.zcolp + cs.x);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        c_rf[u] = rfv[u]; // (used -- and so waited for -- only behind the prefetch below)
+                    for (int u = 0; u < 4; ++u)
+                        c_rp[u] = rfv[u]; // (used -- and so waited for -- only behind the prefetch below)
                     p_own_raw = P[c_desc.z]; // (one more load instead of sixteen selects)
                 }
                 // the next group's descriptors: on their way while this one is worked on
@@ -2503,11 +2504,14 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 if (mine) {
                     if (lane < r) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { // (padding: any finite pi; its factor is 0)
-                            c_pi[2 * u] = pi_s[c_rf[u].x < pb.m ? c_rf[u].x : 0];
-                            c_pi[2 * u + 1] = pi_s[c_rf[u].z < pb.m ? c_rf[u].z : 0];
-                            c_f[2 * u] = (Float)c_rf[u].y;
-                            c_f[2 * u + 1] = (Float)c_rf[u].w;
+                        for (int u = 0; u < 4; ++u) { // (padding: any finite pi; its factor is 0)
+                            const unsigned w4[4] = { c_rp[u].x, c_rp[u].y, c_rp[u].z, c_rp[u].w };
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const int rw_ = (int)(w4[t] & 0xffffu);
+                                c_pi[4 * u + t] = pi_s[rw_ < pb.m ? rw_ : 0];
+                                c_f[4 * u + t] = (Float)(int)(w4[t] >> 16);
+                            }
                         }
                         pik_old = pi_s[k];
                         p_decayed = z_own() * theta; // decrease_preference (stored with affect's value)
