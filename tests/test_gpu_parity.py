@@ -255,6 +255,18 @@ Z_WAVE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("kmax", [65535, 70000], ids=["a-16-bits", "a-beyond-16-bits"])
+def test_z_large_coefficients(oracle, bxh, kmax, monkeypatch):
+    """The wave form reads a slot's row and |coefficient| as one 32-bit word: coefficients of up
+    to 65535 take it, larger ones the plain form (bxh_create decides) -- both equal to the oracle."""
+    monkeypatch.delenv("BXH_ZWAVE", raising=False)
+    monkeypatch.delenv("BXH_GROUPS", raising=False)
+    inst = synth.make_z(100, 700, 0.035, "int", 77, kmax=kmax)
+    assert int(inst.factor.max()) > 60000
+    run_case(oracle, bxh, inst, 1, True, 0, 0.3, batch=2, sweeps=6, push_at=(3,),
+             expect_form=6 if kmax <= 65535 else 3)
+
+
 @pytest.mark.parametrize("zwave", ["wave-per-row", "plain"])
 @pytest.mark.parametrize("case", Z_CASES + Z_WAVE_CASES, ids=[c[0] for c in Z_CASES + Z_WAVE_CASES])
 def test_z_sweeps_match_oracle(oracle, bxh, case, zwave, monkeypatch):
