@@ -201,6 +201,24 @@ bxc_parse(const char* path, bxc_problem_info* info)
     return 0;
 }
 
+// make_problem on a file; the variables' bounds and types as the reader left
+// them (min, max, variable_type), `cap` entries at most.  Returns the status.
+BX_EXPORT int
+bxc_variables(const char* path, int* vmin, int* vmax, int* vtype, int cap)
+{
+    auto ctx = make_context(3);
+    const raw_problem pb = make_problem(ctx, path);
+    if (!pb)
+        return static_cast<int>(pb.status);
+    const int n = std::min(cap, static_cast<int>(pb.vars.values.size()));
+    for (int i = 0; i != n; ++i) {
+        vmin[i] = pb.vars.values[static_cast<size_t>(i)].min;
+        vmax[i] = pb.vars.values[static_cast<size_t>(i)].max;
+        vtype[i] = static_cast<int>(pb.vars.values[static_cast<size_t>(i)].type);
+    }
+    return 0;
+}
+
 // The merged constraints (CSR) and objective of a file, for feeding another
 // solver with exactly what the device gets.  Two calls: buffers null -> sizes.
 BX_EXPORT int

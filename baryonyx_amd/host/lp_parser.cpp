@@ -10,6 +10,7 @@
 #include <cctype>
 #include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <optional>
@@ -244,14 +245,199 @@ struct builder
     }
 };
 
+// static_cast<int>(double) as the reference's build performs it (x86-64
+// cvttsd2si: anything outside int's range, NaN included, gives INT_MIN).
 int
-to_bound(double v)
+to_int(double v)
 {
-    if (v == -std::numeric_limits<double>::infinity())
+    if (!(v > -2147483649.0 && v < 2147483648.0))
         return std::numeric_limits<int>::min();
-    if (v == std::numeric_limits<double>::infinity())
-        return std::numeric_limits<int>::max();
     return static_cast<int>(v);
+}
+
+// lib/src/parser.cpp:540-561 (set_bound_variable): only -inf on the left and
+// +inf on the right are replaced, everything else is cast.
+int
+to_bound_min(double v)
+{
+    return v == -std::numeric_limits<double>::infinity() ? std::numeric_limits<int>::min()
+                                                         : to_int(v);
+}
+
+int
+to_bound_max(double v)
+{
+    return v == std::numeric_limits<double>::infinity() ? std::numeric_limits<int>::max()
+                                                        : to_int(v);
+}
+
+// ---- the bound section, as the reference reads it ---------------------------
+// A bound line is one of (lib/src/parser.cpp:907-965)
+//   l op name op r   -> [l, r]   (l > r is an error)
+//   l op name        -> [l, +inf], and ONE MORE token is consumed (:924-928
+//                       returns read + 1 after read already counts the name)
+//   name op r        -> [0, r]   whatever op is (:944-956): `t = 1` is [0, 1]
+//   name             -> [-inf, +inf]
+// where op is any of < <= =< > >= => = == and is not looked at.  A token is
+// taken for a number by its first character alone -- digits . e E - + or the
+// words inf / infinity (:118-129) -- so a bound on a variable whose name
+// starts with e or E is a bad_bound; `free` is not a keyword of the reference
+// (a variable of that name would be), and the section must be closed by one
+// of the keywords (:152-153): the end of the file is a bad_bound.
+bool
+bound_char_name(int c)
+{
+    if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9'))
+        return true;
+    switch (c) {
+    case '!': case '"': case '#': case '$': case '%': case '&': case '(': case ')':
+    case ',': case '.': case ';': case '?': case '@': case '_': case '{': case '}':
+    case '~':
+        return true;
+    default:
+        return false;
+    }
+}
+
+bool
+bound_keyword(std::string_view t)
+{
+    static const char* const words[] = { "binary", "binaries", "bin",  "bound", "bounds",
+                                         "general", "generals", "gen", "end",   "st",
+                                         "subject", "sush",     "s.t.", "st." };
+    for (auto w : words)
+        if (ieq(t, w))
+            return true;
+    return false;
+}
+
+bool
+bound_starts_with_number(std::string_view t)
+{
+    if (t.empty())
+        return false;
+    if (ieq(t, "infinity") || ieq(t, "inf"))
+        return true;
+    const char c = t[0];
+    return (c >= '0' && c <= '9') || c == '.' || c == 'e' || c == 'E' || c == '-' || c == '+';
+}
+
+bool
+bound_is_name(std::string_view t) // read_name, :612-619: every character a name character
+{
+    for (char c : t)
+        if (!bound_char_name(static_cast<unsigned char>(c)))
+            return false;
+    return true;
+}
+
+std::optional<double>
+bound_real(std::string_view t) // read_real, :565-584: `inf`, else what sscanf("%lf") reads
+{
+    if (ieq(t, "inf"))
+        return std::numeric_limits<double>::infinity();
+    if (t.empty() || t.size() > 319)
+        return std::nullopt;
+    const std::string z(t);
+    double v = 0.0;
+    if (std::sscanf(z.c_str(), "%lf", &v) > 0)
+        return v;
+    return std::nullopt;
+}
+
+int
+bound_operator(std::string_view a, std::string_view b) // tokens of an operator, 0: none (:622-649)
+{
+    if (a == "<" || a == ">")
+        return b == "=" ? 2 : 1;
+    if (a == "=")
+        return (b == "<" || b == "=" || b == ">") ? 2 : 1;
+    return 0;
+}
+
+struct bound_line
+{
+    double min, max;
+    std::string_view name;
+    int read;
+};
+
+struct sub_bound
+{
+    double value;
+    int read;
+};
+
+std::optional<sub_bound>
+read_left_bound(const lexer& lx) // :825-860: [+|-] number op
+{
+    const bool sign = lx.peek(0) == "+" || lx.peek(0) == "-";
+    const size_t at = sign ? 1 : 0;
+    auto v = bound_real(lx.peek(at));
+    if (!v)
+        return std::nullopt;
+    const int op = bound_operator(lx.peek(at + 1), lx.peek(at + 2));
+    if (!op)
+        return std::nullopt;
+    return sub_bound{ lx.peek(0) == "-" ? -*v : *v, static_cast<int>(at) + 1 + op };
+}
+
+std::optional<sub_bound>
+read_right_bound(const lexer& lx, size_t from) // :862-905: op [+|-] number
+{
+    const int op = bound_operator(lx.peek(from), lx.peek(from + 1));
+    if (!op)
+        return std::nullopt;
+    size_t at = from + static_cast<size_t>(op);
+    double negative = 1.0;
+    if (lx.peek(at) == "+" || lx.peek(at) == "-") {
+        if (lx.peek(at) == "-")
+            negative = -1.0;
+        ++at;
+    }
+    auto v = bound_real(lx.peek(at));
+    if (!v)
+        return std::nullopt;
+    return sub_bound{ negative * *v, static_cast<int>(at + 1 - from) };
+}
+
+std::optional<bound_line>
+read_bound(const lexer& lx)
+{
+    constexpr double inf = std::numeric_limits<double>::infinity();
+    const auto first = lx.peek(0);
+    if (bound_starts_with_number(first)) {
+        auto left = read_left_bound(lx);
+        if (!left)
+            return std::nullopt;
+        int read = left->read;
+        const auto name = lx.peek(static_cast<size_t>(read));
+        if (!bound_is_name(name))
+            return std::nullopt;
+        ++read;
+        const auto next = lx.peek(static_cast<size_t>(read));
+        if (next.empty() || !(next[0] == '<' || next[0] == '>' || next[0] == '='))
+            return bound_line{ left->value, inf, name, read + 1 };
+        auto right = read_right_bound(lx, static_cast<size_t>(read));
+        if (!right)
+            return std::nullopt;
+        if (left->value > right->value)
+            return std::nullopt;
+        return bound_line{ left->value, right->value, name, read + right->read };
+    }
+    if (!first.empty() && bound_char_name(static_cast<unsigned char>(first[0]))) {
+        if (!bound_is_name(first))
+            return std::nullopt;
+        const auto next = lx.peek(1);
+        if (!next.empty() && (next[0] == '<' || next[0] == '>' || next[0] == '=')) {
+            auto right = read_right_bound(lx, 1);
+            if (!right)
+                return std::nullopt;
+            return bound_line{ 0.0, right->value, first, 1 + right->read };
+        }
+        return bound_line{ -inf, inf, first, 1 };
+    }
+    return std::nullopt;
 }
 
 // Where a variable already sits in the function being read: (stamp of that
@@ -416,62 +602,21 @@ parse(lexer& lx, builder& b)
     }
 
     // ---- bounds ------------------------------------------------------------
+    // The reference's bound rules, token for token (lib/src/parser.cpp:1213-1226
+    // around read_bound :907-965): the operators of a bound line are read and
+    // ignored.
     if (ieq(lx.peek(), "bounds") || ieq(lx.peek(), "bound")) {
         lx.pop(static_cast<size_t>(keyword_len(lx)));
-        while (!lx.end() && keyword_len(lx) == 0) {
-            double lo = 0.0, hi = std::numeric_limits<double>::infinity();
-            std::string_view name;
-            if (is_name(lx.peek())) {
-                name = lx.peek();
-                lx.pop();
-                if (ieq(lx.peek(), "free")) {
-                    lx.pop();
-                    lo = -std::numeric_limits<double>::infinity();
-                } else if (auto op = read_operator(lx); op) {
-                    auto v = read_signed_number(lx);
-                    if (!v)
-                        return tag::bad_bound;
-                    if (*op == operator_type::less)
-                        hi = *v;
-                    else if (*op == operator_type::greater)
-                        lo = *v;
-                    else
-                        lo = hi = *v;
-                } else {
-                    lo = -std::numeric_limits<double>::infinity();
-                }
-            } else {
-                auto l = read_signed_number(lx);
-                if (!l)
-                    return tag::bad_bound;
-                auto op = read_operator(lx);
-                if (!op || !is_name(lx.peek()))
-                    return tag::bad_bound;
-                name = lx.peek();
-                lx.pop();
-                if (*op == operator_type::less)
-                    lo = *l;
-                else if (*op == operator_type::greater)
-                    hi = *l;
-                else
-                    lo = hi = *l;
-                if (auto op2 = read_operator(lx); op2) {
-                    auto r = read_signed_number(lx);
-                    if (!r)
-                        return tag::bad_bound;
-                    if (*op2 == operator_type::less)
-                        hi = *r;
-                    else if (*op2 == operator_type::greater)
-                        lo = *r;
-                }
-                if (lo > hi)
-                    return tag::bad_bound;
-            }
-            const int id = b.find(name);
+        while (!bound_keyword(lx.peek())) {
+            auto bound = read_bound(lx);
+            if (!bound)
+                return tag::bad_bound;
+            const int id = b.find(bound->name);
             if (id < 0)
                 return tag::bad_bound;
-            b.pb.vars.values[id].min = to_bound(lo);
-            b.pb.vars.values[id].max = to_bound(hi);
+            b.pb.vars.values[id].min = to_bound_min(bound->min);
+            b.pb.vars.values[id].max = to_bound_max(bound->max);
+            lx.pop(static_cast<size_t>(bound->read));
         }
     }
 

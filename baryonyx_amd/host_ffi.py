@@ -79,6 +79,7 @@ def lib():
         L.bxc_default_params.argtypes = [C.POINTER(Params)]
         L.bxc_parse.argtypes = [C.c_char_p, C.POINTER(ProblemInfo)]
         ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        L.bxc_variables.argtypes = [C.c_char_p, ip, ip, ip, C.c_int]
         L.bxc_merged.argtypes = [C.c_char_p, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, dp, dp, ip, ip,
                                  ip, ip, ip, dp]
         L.bxc_preprocess.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PreprocessInfo), C.c_int, C.c_int,
@@ -165,6 +166,21 @@ def parse(path) -> ProblemInfo:
     info = ProblemInfo()
     lib().bxc_parse(os.fsencode(path), C.byref(info))
     return info
+
+
+def variables(path):
+    """[(min, max, variable_type)] of an LP file's variables in order of first
+    appearance, as make_problem leaves them; raises with the reader's status."""
+    info = parse(path)
+    if info.status != 0:
+        raise ValueError(info.status)
+    n = max(info.variables, 1)
+    lo, hi, ty = (np.zeros(n, np.int32) for _ in range(3))
+    ip = C.POINTER(C.c_int)
+    rc = lib().bxc_variables(os.fsencode(path), lo.ctypes.data_as(ip), hi.ctypes.data_as(ip),
+                             ty.ctypes.data_as(ip), n)
+    assert rc == 0
+    return [(int(lo[i]), int(hi[i]), int(ty[i])) for i in range(info.variables)]
 
 
 def merged(path, pre_order=0, preprocessor=1):

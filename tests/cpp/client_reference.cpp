@@ -140,6 +140,7 @@ main(int argc, char** argv)
                             r.affected_vars.names[i].data(), static_cast<int>(r.affected_vars.values[i]));
             std::printf("\n");
         });
+        run("capmo1_direct" + s, g_lp + "/capmo1_direct.lp", defaults);          // :197-240
         run("quadratic" + s, inline_file("quadratic", quad), defaults);        // :242-259
         run("real_cost" + s, inline_file("real_cost", real_cost), defaults);    // :261-290
         run("assignment" + s, g_lp + "/assignment_problem_1.lp", defaults);     // :292-303

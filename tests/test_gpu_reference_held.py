@@ -81,6 +81,18 @@ def test_preprocessor(client, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", SEEDS)
+def test_preprocessor_2(client, oracle, seed):
+    """solve.cpp:197-240 (capmo1_direct.lp, default parameters): success, valid,
+    recomputed value == value, **value < 1 156 908** (:217); and the oracle's
+    point."""
+    c = client[0][f"capmo1_direct-s{seed}"]
+    _ok(c)
+    assert float(c["value"]) < 1156908
+    assert c["affected"] == "1"  # `t`: [0, 1] by parser.cpp:944-956, in no constraint, cost > 0 -> 0
+    _same_as_oracle(oracle, c, H.merged(os.path.join(LP, "capmo1_direct.lp")), seed, {})
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 @pytest.mark.parametrize("name,text,raw", [
     ("real_cost", T.REAL_COST, {}), ("negative-coeff5", T.NEGATIVE_COEFF5, {}),
     ("z_coefficient_a", T.Z_COEFFICIENT_A, {}), ("z_coefficient_b", T.Z_COEFFICIENT_B, {}),

@@ -183,3 +183,90 @@ def test_parameter_validation_matches_the_restatement():
             assert a == b or (isinstance(b, float) and math.isinf(b) and math.isinf(a)), (raw, f, a, b)
         count += 1
     assert count == 4 * 5 * 6 * 2 * 3 * 2
+
+
+INT_MIN, INT_MAX = -2 ** 31, 2 ** 31 - 1
+BAD_BOUND = 8  # file_format_error_tag::bad_bound
+
+
+def _bounds_file(tmp_path, lines, tail="end\n"):
+    p = tmp_path / "b.lp"
+    p.write_text("minimize\nx + y + z + e1\nst\nx + y + z + e1 >= 1\nbounds\n" + lines + "\n" + tail)
+    return str(p)
+
+
+@pytest.mark.parametrize("lines,expected", [
+    # name op v -> [0, v]: the operator is read and ignored (parser.cpp:944-956)
+    ("x <= 40", {"x": (0, 40)}),
+    ("x >= 3", {"x": (0, 3)}),
+    ("x = 1", {"x": (0, 1)}),                      # capmo1_direct.lp:13726 `t = 1`
+    ("x = 0", {"x": (0, 0)}),                      # prepro.lp:22 `t = 0`
+    ("x == 7\ny =< 5\nz => 6", {"x": (0, 7), "y": (0, 5), "z": (0, 6)}),
+    ("x < 4\ny > 4", {"x": (0, 4), "y": (0, 4)}),
+    ("x <= -2", {"x": (0, -2)}),                   # no order check on this form
+    ("x <= + 8\ny <= - 8", {"x": (0, 8), "y": (0, -8)}),
+    ("x <= 2.7\ny <= -2.7\nz <= 1e3", {"x": (0, 2), "y": (0, -2), "z": (0, 1000)}),  # static_cast<int>
+    ("x <= inf\ny <= infinity\nz <= -inf", {"x": (0, INT_MAX), "y": (0, INT_MAX), "z": (0, INT_MIN)}),
+    # l op name op r -> [l, r] (:910-942)
+    ("2 <= x <= 9", {"x": (2, 9)}),
+    ("2 >= x >= 9", {"x": (2, 9)}),
+    ("2 = x = 9", {"x": (2, 9)}),
+    ("- 3 <= x <= - 1\n+ 1 <= y <= + 2", {"x": (-3, -1), "y": (1, 2)}),
+    ("-inf <= x <= 5\n-5 <= y <= inf\n- infinity <= z <= infinity",
+     {"x": (INT_MIN, 5), "y": (-5, INT_MAX), "z": (INT_MIN, INT_MAX)}),
+    ("1.9 <= x <= 9.9", {"x": (1, 9)}),
+    # a bare name -> free (:958-961)
+    ("x\ny <= 3", {"x": (INT_MIN, INT_MAX), "y": (0, 3)}),
+    # l op name -> [l, +inf] and the NEXT token goes with it (:924-928 returns read + 1)
+    ("3 <= x\ny\nz <= 2", {"x": (3, INT_MAX), "y": (0, INT_MAX), "z": (0, 2)}),
+    # the last line for a variable wins; an empty section changes nothing
+    ("x <= 4\nx <= 6", {"x": (0, 6)}),
+    ("", {}),
+])
+def test_bound_forms_follow_the_reference(tmp_path, lines, expected):
+    """lib/src/parser.cpp:907-965 (read_bound) with :540-561 (set_bound_variable)."""
+    path = _bounds_file(tmp_path, lines)
+    assert H.parse(path).status == 0
+    got = dict(zip(["x", "y", "z", "e1"], H.variables(path)))
+    for name in ("x", "y", "z", "e1"):
+        lo, hi = expected.get(name, (0, INT_MAX))
+        assert got[name] == (lo, hi, 0), (name, got[name])
+
+
+@pytest.mark.parametrize("lines,tail", [
+    ("9 <= x <= 2", "end\n"),          # l > r (:936-937)
+    ("3 <= x", "end\n"),               # the left-only form takes `end` with it; the file's end is no keyword
+    ("x free", "end\n"),               # `free` is not a keyword of the reference: an unknown variable
+    ("e1 <= 4", "end\n"),              # first character e: taken for a number (:118-129), sscanf fails
+    ("E1 <= 4", "end\n"),
+    ("w <= 4", "end\n"),               # unknown variable (:542-544)
+    ("x <= y", "end\n"),               # no number behind the operator
+    ("x <=", "end\n"),
+    ("<= 4", "end\n"),
+    ("2 x <= 4", "end\n"),             # a number must be followed by an operator
+    ("x|y <= 4", "end\n"),             # `|` is no name character (:68-96)
+    ("x <= 4", ""),                    # no keyword closes the section (:1216)
+])
+def test_bad_bounds(tmp_path, lines, tail):
+    assert H.parse(_bounds_file(tmp_path, lines, tail)).status == BAD_BOUND
+
+
+def test_binary_section_overrides_bounds(tmp_path):
+    """set_boolean_variable (parser.cpp:507-516) runs after the bounds."""
+    path = _bounds_file(tmp_path, "x <= 40\n2 <= y <= 9", "binary\nx\ngeneral\ny\nend\n")
+    v = H.variables(path)
+    assert v[0] == (0, 1, 1) and v[1] == (2, 9, 2) and v[2] == (0, INT_MAX, 0)
+
+
+def test_fixture_bound_sections():
+    """What the reference's io tests hold (lib/test/io.cpp:143-149, :699-704) and
+    the two bound lines its solver tests depend on."""
+    for lo, hi, ty in H.variables(lp("sudoku.lp")):
+        assert (lo, hi, ty) == (1, 9, 2)
+    assert all(v == (0, 1, 2) for v in H.variables(lp("general.lp")))
+    # prepro.lp: `t = 0` -> [0, 0], then `binaries ... t` -> [0, 1]
+    assert all(v == (0, 1, 1) for v in H.variables(lp("prepro.lp")))
+    # capmo1_direct.lp: `t = 1` -> [0, 1], t in no constraint and not binary
+    caps = H.variables(lp("capmo1_direct.lp"))
+    assert sum(1 for v in caps if v[2] != 1) == 1
+    assert [v for v in caps if v[2] != 1] == [(0, 1, 0)]

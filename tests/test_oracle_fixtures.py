@@ -102,19 +102,20 @@ def test_synthetic_families_solve(oracle, maker):
 def test_capmo1_direct_default_solve(oracle, seed, sort_mode):
     """lib/test/solve.cpp:197-240 (`test_preprocessor_2`): solve() with the
     default parameters on capmo1_direct.lp (10 100 merged constraints,
-    inequalities-01; the reference seeds from the clock) must give a valid
-    solution whose recomputed value equals the reported one.  Pinned here on the
-    restatement for three seeds.
+    inequalities-01; the reference seeds from the clock, here three fixed
+    seeds) must give a valid solution whose recomputed value equals the reported
+    one and is **below 1 156 908** (solve.cpp:217).
 
-    The reference's third expectation, `value < 1156908`, is NOT reproduced: the
-    values found (7.3 - 7.9e6 for these seeds) are of the size the test's own
-    print statement names ("result.value ... == 6212977"), both far above that
-    bound.  The reference cannot be run here to see whether its `expect` passes
-    (a failing boost.ut `expect` does not abort the test); recorded as an open
-    difference in DESIGN.md section 4."""
+    The file's bound section says `t = 1` for a variable of cost +14 156 111
+    that is in no constraint.  The reference reads that line as [0, 1]
+    (parser.cpp:944-956: the operator is ignored), its preprocessor fixes the
+    unused positive-cost variable at 0, and the value stays negative.  (Rounds
+    1 - 4 read `t = 1` as a fixed variable and sat 14 156 111 above.)"""
     inst = H.merged(os.path.join(LP, "capmo1_direct.lp"))
     assert (inst.m, inst.n, inst.kind) == (10100, 10100, 1)
+    assert inst.obj_constant == 0.0
     res, xw = oracle.solve(inst, 1, oracle.default_params(seed=seed, sort_mode=sort_mode))
     assert res.status == 0
     assert is_feasible(inst, xw)
     assert res.value == objective(inst, xw)
+    assert res.value < 1156908  # solve.cpp:217

@@ -163,6 +163,20 @@ def test_preprocessor_on_prepro_lp(oracle):
 
 
 @pytest.mark.parametrize("seed", SEEDS)
+def test_preprocessor_2_capmo1_direct(oracle, seed):
+    """solve.cpp:197-240: default parameters on capmo1_direct.lp -> success, a
+    valid point, recomputed value == value and value < 1 156 908 (:217).  The
+    last one depends on the reference's reading of the bound line `t = 1` as
+    [0, 1] (parser.cpp:944-956), which leaves the unused variable t (cost
+    14 156 111) to the preprocessor, at 0."""
+    inst = H.merged(os.path.join(LP, "capmo1_direct.lp"))
+    for sort_mode in (0, 1):
+        res, xw = oracle.solve(inst, 1, oracle.default_params(seed=seed, sort_mode=sort_mode))
+        _expect_success_and_valid(inst, res, xw)
+        assert res.value < 1156908
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_assignment_problem(oracle, seed):
     """solve.cpp:292-303: success with the default parameters."""
     inst = H.merged(os.path.join(LP, "assignment_problem_1.lp"))
@@ -343,10 +357,6 @@ def test_qap_optimize_with_the_reference_tests_parameters(oracle):
 #   its only assertion with `if (result)`: its authors do not expect success
 #   there either.  testoptimizer is excluded from the reference's CI
 #   (.travis.yml:100-111 `ctest -E testoptimizer`).
-# * solve.cpp:217 `value < 1156908` on capmo1_direct.lp (the print statement
-#   one line above says "== 6212977"): tests/test_oracle_fixtures.py
-#   ::test_capmo1_direct_default_solve keeps the three assertions that hold
-#   (success, valid, recomputed value) and documents the fourth.
 # * optimize.cpp:152-163 `mean_distance >= 0` over the n-queens files: a
 #   minimisation's feasible value is never below the optimum, so the sum of
 #   (cplex - value) / cplex is >= 0 only when every value is optimal.  The
