@@ -33,7 +33,7 @@ SYMBOLS = [
     "bxh_nwords", "bxh_rmax", "bxh_kernel_form", "bxh_sweep_includes_scan", "bxh_run_supported", "bxh_run", "bxh_get_best_x", "bxh_set_x", "bxh_get_x", "bxh_set_x_all", "bxh_get_x_all", "bxh_set_rng_all", "bxh_pop_create", "bxh_pop_set", "bxh_pop_get", "bxh_pop_store", "bxh_reinit", "bxh_set_pi", "bxh_get_pi",
     "bxh_set_P", "bxh_get_P", "bxh_set_rng", "bxh_get_rng", "bxh_reset", "bxh_reset_all",
     "bxh_order_create", "bxh_order_init", "bxh_order_init_masked", "bxh_get_violated", "bxh_sweep", "bxh_sweep_async",
-    "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time",
+    "bxh_status_sync", "bxh_row_bytes", "bxh_kernel_time", "bxh_set_objective", "bxh_incumbent",
 ]
 
 
@@ -167,6 +167,8 @@ def lib():
         L.bxh_status_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.bxh_row_bytes.argtypes = [C.c_void_p, f64p]
         L.bxh_kernel_time.argtypes = [C.c_void_p, f64p, u64p, C.c_int]
+        L.bxh_set_objective.argtypes = [C.c_void_p, f64p, C.c_double, C.c_int]
+        L.bxh_incumbent.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -191,6 +193,10 @@ class RunArgs(C.Structure):
                 ("order", C.c_int), ("max_sweeps", C.c_int), ("first_i", C.c_int), ("w_limit", C.c_int),
                 ("kappa_max", C.c_double), ("kappa_inc", C.POINTER(C.c_double)),
                 ("active", C.POINTER(C.c_ubyte))]
+
+
+INCUMBENT_DTYPE = np.dtype([("key_hi", np.int64), ("key_lo", np.int64), ("value", np.float64),
+                            ("remaining", np.int32), ("instance", np.int32)])  # bxh_incumbent_record
 
 
 RUN_STATUS_DTYPE = np.dtype([("sweeps", np.int32), ("best_remaining", np.int32), ("best_i", np.int32),
@@ -333,6 +339,24 @@ class DeviceBatch:
         w = np.zeros((self.batch, self.nwords), np.uint64)
         _check(self.L.bxh_get_x_all(self.h, _p(w, u64p)))
         return w
+
+    def set_objective(self, cost, constant=0.0, maximize=False):
+        """The ORIGINAL linear costs (Cost::results sums those), once, for incumbent()."""
+        c = np.ascontiguousarray(cost, np.float64)
+        assert c.shape == (self.n,)
+        _check(self.L.bxh_set_objective(self.h, _p(c, f64p), float(constant), int(bool(maximize))))
+
+    def incumbent(self, rank=0, record_device=None, x_device=None, read_back=True):
+        """bxh_incumbent: the batch's best instance (fewest violated rows, then the
+        objective), found on the device.  record_device / x_device: device pointers
+        (ints) that receive the 32-byte record and the winner's x in stream order;
+        read_back: also return the record (one 32-byte transfer), else None."""
+        rec = np.zeros(1, INCUMBENT_DTYPE) if read_back else None
+        _check(self.L.bxh_incumbent(
+            self.h, int(rank), C.c_void_p(int(record_device) if record_device else None),
+            C.c_void_p(int(x_device) if x_device else None),
+            rec.ctypes.data_as(C.c_void_p) if read_back else None))
+        return rec[0] if read_back else None
 
     def set_rng_all(self, states):
         s = np.ascontiguousarray(states, np.uint32)

@@ -10,6 +10,7 @@
 #include "bxh_narrow.hpp"
 #include "bxh_swave.hpp"
 #include "bxh_wide_build.hpp"
+#include "bxh_incumbent.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -380,6 +381,25 @@ struct bxh_handle_s
     double* h_kappa = nullptr;          // pinned
     unsigned char* h_active = nullptr;  // pinned
 
+    // bxh_sweep_async's uploads (kappa, and the active mask behind it) leave from a
+    // ring of pinned slots in ONE copy per call: a call waits for the copy that used
+    // its slot kStageSlots calls ago, not for the previous launch
+    static constexpr int kStageSlots = 8;
+    unsigned char* h_stage[kStageSlots] = {};
+    hipEvent_t stage_done[kStageSlots] = {};
+    bool stage_busy[kStageSlots] = {};
+    size_t stage_seq = 0;
+    DevBuf<unsigned char> sargs;  // [batch] double kappa, then [batch] active
+    std::vector<int> ostate_dev;  // order_b as uploaded last
+
+    // bxh_incumbent
+    DevBuf<double> obj_cost, inc_value;
+    DevBuf<bxh::IncumbentRecord> inc_rec;
+    DevBuf<unsigned> inc_x;
+    double obj_constant = 0.0;
+    int obj_maximize = 0;
+    bool obj_set = false;
+
     bxh::DevProblem dp{};
     bxh::DevState ds{};
 
@@ -393,6 +413,12 @@ struct bxh_handle_s
             (void)hipHostFree(h_active);
         if (h_order)
             (void)hipHostFree(h_order);
+        for (int i = 0; i != kStageSlots; ++i) {
+            if (h_stage[i])
+                (void)hipHostFree(h_stage[i]);
+            if (stage_done[i])
+                (void)hipEventDestroy(stage_done[i]);
+        }
         for (auto& ev : events) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
@@ -415,6 +441,29 @@ check_inst(bxh_handle h, int inst)
     if (e != hipSuccess)
         return fail(BXH_ERR_DEVICE, hipGetErrorString(e));
     return BXH_OK;
+}
+
+// Compute units of a device, asked once per device (hipGetDeviceProperties costs
+// milliseconds; bxh_create needs the number in several places and optimize() may
+// create one handle per worker).
+int
+device_cus(int device)
+{
+    static std::mutex mu;
+    static std::vector<int> known;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0)
+        return 256;
+    if (static_cast<size_t>(device) >= known.size())
+        known.resize(static_cast<size_t>(device) + 1, 0);
+    int& cus = known[static_cast<size_t>(device)];
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount
+                : 256;
+    }
+    return cus;
 }
 
 template<typename Float>
@@ -474,6 +523,21 @@ drain_events(bxh_handle h)
         ++h->kernel_launches;
     }
     h->events_used = 0;
+    return BXH_OK;
+}
+
+// The device copy of the per-instance row orders follows the host's (`ostate`):
+// uploaded only when it differs from what was uploaded last.
+int
+sync_order_b(bxh_handle h)
+{
+    if (h->ostate_dev == h->ostate)
+        return BXH_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream)); // the pinned buffer is reused
+    std::memcpy(h->h_order, h->ostate.data(), static_cast<size_t>(h->batch) * sizeof(int));
+    HIP_TRY(hipMemcpyAsync(h->order_b.p, h->h_order, static_cast<size_t>(h->batch) * sizeof(int),
+                           hipMemcpyHostToDevice, h->stream));
+    h->ostate_dev = h->ostate;
     return BXH_OK;
 }
 
@@ -727,10 +791,7 @@ bxh_create(const bxh_problem* pb,
         const bool asked = eg && eg[0] == 'w';
         const bool fits_v2 = cmax <= 128 && m < 32768;
         if (!zsolver && pb->n_quad == 0 && (asked || (!fits_v2 && !(force_v1 && force_v1[0] == '1')))) {
-            int cus = 256;
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-                cus = prop.multiProcessorCount;
+            const int cus = device_cus(device);
             // every workgroup should get a tile (32 columns) per wave of the longest row
             wide_g = std::max(1, std::min({ cus / batch, rmax / 256, 64 }));
             if (asked && std::atoi(eg + 1) > 0)
@@ -752,10 +813,6 @@ bxh_create(const bxh_problem* pb,
         int rmin = m > 0 ? rmax : 0;
         for (int k = 0; k != m; ++k)
             rmin = std::min(rmin, pb->row_ptr[k + 1] - pb->row_ptr[k]);
-        int cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
         const char* es = std::getenv("BXH_SWAVE");
         const bool fits = !zsolver && !wide_g && pb->n_quad == 0 && rmin >= 1 && rmax <= 63 && m >= 1 && m < 32768 &&
                           bxh::sw_lds(m, h->nwords, rmax, float_type == BXH_FLOAT ? 4 : 8).total <= 160 * 1024 &&
@@ -765,7 +822,6 @@ bxh_create(const bxh_problem* pb,
         // bxh_run.  164 registers: three workgroups share a CU, and the form stays ahead of the
         // one-wave kernel at every batch size measured -- c1 at 512 / 1024 / 2048 restarts
         // 249 / 272 / 341 against 135 / 264 / 275 M row-updates/s)
-        (void)cus;
         swave = fits && (es ? es[0] == '1' : m >= 64);
     }
     bool narrow = false;
@@ -781,10 +837,7 @@ bxh_create(const bxh_problem* pb,
     const bool v2_ok = !swave && !narrow && !wide_g && !zsolver && cmax <= 128 && m < 32768 && !(force_v1 && force_v1[0] == '1');
     int groups = 1;
     if (v2_ok) {
-        int cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
+        const int cus = device_cus(device);
         // ... and only while every owner still gets a full round of 128 columns of
         // the longest row: below that the exchange costs more than the split saves
         // (measured: rows of 20 and of 120 elements run 10-20 % faster with one owner)
@@ -807,10 +860,7 @@ bxh_create(const bxh_problem* pb,
         int want = 0;
         const char* eg = std::getenv("BXH_GROUPS");
         const char* ep = std::getenv("BXH_PIPE");
-        int cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
+        const int cus = device_cus(device);
         if (eg && eg[0] == 'p')
             want = std::atoi(eg + 1);
         else if (!eg && groups == 4 && !(ep && ep[0] == '0'))
@@ -1160,18 +1210,24 @@ bxh_create(const bxh_problem* pb,
             // registers: one workgroup per CU.  Beyond two workgroups per CU the plain form, two
             // to a CU, is ahead again -- c5 at 1024 restarts: 112 against 76 M row-updates/s.)
             const char* ez = std::getenv("BXH_ZWAVE");
-            int cus = 256;
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-                cus = prop.multiProcessorCount;
+            const int cus = device_cus(device);
             h->zwave = (pb->n_quad == 0 && batch <= 2 * cus) ? 1 : 0;
-            if (ez)
+            if (ez) {
                 h->zwave = (ez[0] != '0' && pb->n_quad == 0) ? 1 : 0;
+                if (h->zwave && batch > 2 * cus)
+                    std::fprintf(stderr, "libbxh: BXH_ZWAVE forces the wave form at %d instances on %d CUs; "
+                                         "beyond two workgroups per CU the plain form is the faster one\n",
+                                 batch, cus);
+            }
             if (h->zwave &&
                 bxh::lds_bytes_z(m, h->nwords, rmax, static_cast<int>(h->fsize), true) > lds_limit)
                 h->zwave = 0;
-            // (the wave form reads a slot's row and |coefficient| as one 32-bit word)
-            if (h->zwave && (m > 65535 || *std::max_element(col_fac.begin(), col_fac.end()) > 65535))
+            // (the wave form reads a slot's row and |coefficient| as one 32-bit word, and its
+            // 32-byte descriptor keeps the padded column length in 16 bits: rows, coefficients
+            // and the longest padded column must all stay below 65536 -- a column has at most
+            // m entries, padded to the next multiple of 16)
+            if (h->zwave && (m > 65535 || ((cmax + 15) & ~15) > 65535 ||
+                             *std::max_element(col_fac.begin(), col_fac.end()) > 65535))
                 h->zwave = 0;
         }
         const int zl = bxh::lds_bytes_z(m, h->nwords, rmax, static_cast<int>(h->fsize), h->zwave != 0);
@@ -1259,10 +1315,7 @@ bxh_create(const bxh_problem* pb,
         // more instances than CUs, and two LDS plans fit a CU: the 256-register build, two
         // workgroups per CU (BXH_NARROW_OCC=1 / 2 decides otherwise)
         {
-            int cus = 256;
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-                cus = prop.multiProcessorCount;
+            const int cus = device_cus(device);
             h->narrow_occ2 = h->narrow_w == 4 && h->narrow_rph >= 3 && batch > cus && 2 * h->lds_bytes <= 160 * 1024;
             if (const char* eo = std::getenv("BXH_NARROW_OCC"))
                 h->narrow_occ2 = h->narrow_w == 4 && h->narrow_rph >= 3 && eo[0] == '2';
@@ -1637,10 +1690,8 @@ bxh_create(const bxh_problem* pb,
     // inside the launch: every workgroup of the grid must be resident at once.
     // Ask the runtime how many workgroups of this kernel one CU takes.
     if (wide_g || h->pipe || groups > 1) {
-        int per_cu = 0, cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
+        int per_cu = 0;
+        const int cus = device_cus(device);
         const void* fn = nullptr;
         if (wide_g)
             fn = float_type == BXH_FLOAT
@@ -1934,12 +1985,7 @@ bxh_create_device(const bxh_problem* pb,
     }
 
     // ---- geometry of the wide kernel -----------------------------------------
-    int cus = 256;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-    }
+    const int cus = device_cus(device);
     int wide_g = std::max(1, std::min({ cus / batch, rmax / 256, 64 })); // (a small batch: at most 64 per instance)
     if (const char* eg = std::getenv("BXH_GROUPS"))
         if (eg[0] == 'w' && std::atoi(eg + 1) > 0)
@@ -2502,6 +2548,7 @@ bxh_order_create(bxh_handle h, int order)
     std::vector<int> cnt(B, h->n);
     HIP_TRY(hipMemcpy(h->mcount.p, cnt.data(), B * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->order_b.p, h->ostate.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    h->ostate_dev = h->ostate;
     return BXH_OK;
 }
 
@@ -2522,8 +2569,10 @@ bxh_order_init_masked(bxh_handle h, int order, const uint8_t* active, int32_t* r
             h->known_empty[static_cast<size_t>(b)] = 0;
             h->skipped[static_cast<size_t>(b)] = 0;
         }
-    // (the device copy of the per-instance orders is current: it is written
-    // by bxh_order_create and by every sweep)
+    // (the device copy of the per-instance orders: written by bxh_order_create,
+    // and by a sweep whenever a `cycle` order moved on)
+    if (int rc = sync_order_b(h))
+        return rc;
     const unsigned char* dev_active = nullptr;
     if (active) {
         HIP_TRY(hipStreamSynchronize(h->stream)); // the pinned buffer is reused
@@ -2659,19 +2708,7 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
             return fail(BXH_ERR_INVALID, "kappa must not be negative");
     HIP_TRY(hipSetDevice(h->device));
 
-    // the pinned staging buffers are reused by the next call: wait for the
-    // previous upload to have been consumed
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (int rc = drain_events(h))
-        return rc;
-    std::memcpy(h->h_kappa, a->kappa, static_cast<size_t>(h->batch) * sizeof(double));
-    HIP_TRY(hipMemcpyAsync(h->kappa.p,
-                           h->h_kappa,
-                           static_cast<size_t>(h->batch) * sizeof(double),
-                           hipMemcpyHostToDevice,
-                           h->stream));
     bxh::DevSweep s;
-    s.kappa = h->kappa.p;
     s.delta = a->delta;
     s.theta = a->theta;
     s.obj_amp = a->obj_amp;
@@ -2710,21 +2747,45 @@ bxh_sweep_async(bxh_handle h, const bxh_sweep_args* a)
         if (all_empty)
             return BXH_OK;
     }
-    std::memcpy(h->h_order, h->ostate.data(), static_cast<size_t>(h->batch) * sizeof(int));
-    HIP_TRY(hipMemcpyAsync(h->order_b.p, h->h_order, static_cast<size_t>(h->batch) * sizeof(int),
-                           hipMemcpyHostToDevice, h->stream));
+    // The call's uploads: kappa and the active mask in ONE copy from the next
+    // pinned slot of the ring (the slot's previous copy, kStageSlots calls ago,
+    // must have been consumed: no wait for the previous LAUNCH); the
+    // per-instance orders only when they changed (a `cycle` order's push).
+    {
+        const size_t B = static_cast<size_t>(h->batch);
+        if (!h->sargs.p) {
+            HIP_TRY(h->sargs.alloc(B * 9));
+            for (int i = 0; i != bxh_handle_s::kStageSlots; ++i) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage[i]), B * 9, hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming));
+            }
+        }
+        const int slot = static_cast<int>(h->stage_seq++ % bxh_handle_s::kStageSlots);
+        if (h->stage_busy[slot])
+            HIP_TRY(hipEventSynchronize(h->stage_done[slot]));
+        unsigned char* hs = h->h_stage[slot];
+        std::memcpy(hs, a->kappa, B * sizeof(double));
+        size_t bytes = B * sizeof(double);
+        s.active = nullptr;
+        if (a->active) {
+            std::memcpy(hs + bytes, a->active, B);
+            s.active = h->sargs.p + bytes;
+            bytes += B;
+        }
+        HIP_TRY(hipMemcpyAsync(h->sargs.p, hs, bytes, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipEventRecord(h->stage_done[slot], h->stream));
+        h->stage_busy[slot] = true;
+        s.kappa = reinterpret_cast<const double*>(h->sargs.p);
+        if (int rc = sync_order_b(h))
+            return rc;
+        if (h->events_used >= 256) { // bound the list of timing events: fold the finished ones
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (int rc = drain_events(h))
+                return rc;
+        }
+    }
     s.order = 0;
     s.order_b = h->order_b.p;
-    s.active = nullptr;
-    if (a->active) {
-        std::memcpy(h->h_active, a->active, static_cast<size_t>(h->batch));
-        HIP_TRY(hipMemcpyAsync(h->active.p,
-                               h->h_active,
-                               static_cast<size_t>(h->batch),
-                               hipMemcpyHostToDevice,
-                               h->stream));
-        s.active = h->active.p;
-    }
     if (h->version == 4) // arrival counters of the wide kernel's workgroups (the error word stays)
         HIP_TRY(hipMemsetAsync(h->wcnt.p, 0, 4 * static_cast<size_t>(h->batch) * sizeof(unsigned),
                                h->stream));
@@ -2911,6 +2972,55 @@ bxh_sweep(bxh_handle h, const bxh_sweep_args* a, bxh_status* out)
     if (int rc = bxh_sweep_async(h, a))
         return rc;
     return bxh_status_sync(h, out);
+}
+
+int
+bxh_set_objective(bxh_handle h, const double* cost_n, double constant, int maximize)
+{
+    if (!h || !cost_n)
+        return fail(BXH_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = static_cast<size_t>(h->n), B = static_cast<size_t>(h->batch);
+    if (!h->obj_cost.p) {
+        HIP_TRY(h->obj_cost.alloc(n));
+        HIP_TRY(h->inc_value.alloc(B));
+        HIP_TRY(h->inc_rec.alloc(1));
+        HIP_TRY(h->inc_x.alloc(2 * static_cast<size_t>(h->nwords)));
+        HIP_TRY(hipStreamSynchronize(nullptr)); // (DevBuf::alloc's fills run on the null stream)
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->obj_cost.p, cost_n, n * sizeof(double), hipMemcpyHostToDevice));
+    h->obj_constant = constant;
+    h->obj_maximize = maximize ? 1 : 0;
+    h->obj_set = true;
+    return BXH_OK;
+}
+
+int
+bxh_incumbent(bxh_handle h, int rank, void* record_device, void* x_device, bxh_incumbent_record* record_host)
+{
+    static_assert(sizeof(bxh_incumbent_record) == sizeof(bxh::IncumbentRecord), "ABI");
+    if (!h)
+        return fail(BXH_ERR_INVALID, "null handle");
+    if (!h->obj_set)
+        return fail(BXH_ERR_INVALID, "bxh_incumbent: bxh_set_objective first");
+    if (rank < 0 || rank >= (1 << bxh::kIncRankBits))
+        return fail(BXH_ERR_INVALID, "bxh_incumbent: the key has room for ranks 0 .. 63");
+    HIP_TRY(hipSetDevice(h->device));
+    bxh::IncumbentRecord* rec =
+      record_device ? static_cast<bxh::IncumbentRecord*>(record_device) : h->inc_rec.p;
+    unsigned* xo = x_device ? static_cast<unsigned*>(x_device) : h->inc_x.p;
+    hipLaunchKernelGGL(bxh::incumbent_value_kernel, dim3(h->batch), dim3(256), 0, h->stream, h->x.p, h->nwords,
+                       h->n, h->obj_cost.p, h->obj_constant, h->inc_value.p);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(bxh::incumbent_pick_kernel, dim3(1), dim3(256), 0, h->stream, h->status.p,
+                       h->inc_value.p, h->x.p, h->batch, h->nwords, h->obj_maximize, rank, rec, xo);
+    HIP_TRY(hipGetLastError());
+    if (record_host) {
+        HIP_TRY(hipMemcpyAsync(record_host, rec, sizeof(bxh::IncumbentRecord), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return BXH_OK;
 }
 
 int

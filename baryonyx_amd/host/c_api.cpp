@@ -48,6 +48,16 @@ struct bxc_result
 
 // wall-clock phases of the calling thread's last optimize(): host set-up,
 // device set-up, rounds (seconds)
+// ... and, of the rounds, the host's share outside its wait for the device
+// (seconds) with the number of rounds
+BX_EXPORT void
+bxc_last_optimize_host_rounds(double* seconds, long long* rounds)
+{
+    const optimize_timing& t = last_optimize_timing();
+    *seconds = t.rounds_host;
+    *rounds = t.round_count;
+}
+
 BX_EXPORT void
 bxc_last_optimize_timing(double* out3)
 {

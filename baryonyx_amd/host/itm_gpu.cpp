@@ -1554,6 +1554,7 @@ optimize_problem(const context& ctx, const problem& pb)
             break;
         if (sweeps >= sweep_budget)
             break;
+        const double t_round = elapsed();
 
         // -- restarts (reinit + compute.init), per worker in id order --------
         if (device_population)
@@ -1608,7 +1609,9 @@ optimize_problem(const context& ctx, const problem& pb)
             slv.sweep_async(static_cast<double>(delta), static_cast<double>(theta), push,
                             push ? static_cast<double>(pushing_objective_amplifier) : 0.0, order);
         }
+        const double t_wait = elapsed();
         slv.sync();
+        const double t_back = elapsed();
         for (int b = 0; b != workers; ++b) {
             if (!swept[static_cast<size_t>(b)])
                 continue;
@@ -1679,6 +1682,8 @@ optimize_problem(const context& ctx, const problem& pb)
                 slv.set_rng(b, lctx[b].rng);
         }
         ++sweeps;
+        tm.rounds_host += (t_wait - t_round) + (elapsed() - t_back);
+        ++tm.round_count;
 
         if (ctx.update && elapsed() >= next_update) {
             next_update += 1.0;

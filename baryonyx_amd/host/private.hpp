@@ -52,6 +52,10 @@ struct context
 struct optimize_timing
 {
     double host_setup = 0, device_setup = 0, rounds = 0;
+    // of `rounds`: what the host spends outside its wait for the device -- the
+    // restarts' bookkeeping, the launches, the recorder's updates
+    double rounds_host = 0;
+    long round_count = 0;
 };
 optimize_timing& last_optimize_timing();
 

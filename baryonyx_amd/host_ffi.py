@@ -269,6 +269,14 @@ def last_optimize_timing():
     return float(out[0]), float(out[1]), float(out[2])
 
 
+def last_optimize_host_rounds():
+    """(host seconds inside the rounds of this thread's last optimize() that were not
+    spent waiting for the device, rounds)."""
+    sec, n = C.c_double(), C.c_longlong()
+    lib().bxc_last_optimize_host_rounds(C.byref(sec), C.byref(n))
+    return sec.value, n.value
+
+
 def optimize_trace(path, params, nvars):
     """baryonyx::optimize with the recorder's final state: (Result, dict) with
     the population best first (x over the `nvars` preprocessed variables), every

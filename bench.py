@@ -107,6 +107,9 @@ def kappa_cycle(params, k):
     return params.kappa_min + (params.kappa_max - params.kappa_min) * app
 
 
+CPU_SORT_MODE = 0  # the oracle's SORT_STD (the reference's own std::sort); 1 = the canonical stable rule
+
+
 def cpu_run(inst, params, float_type, seconds, nthreads, rows=None):
     """The same restart-sweep workload on host threads: every thread owns one
     oracle Solver (as every reference worker owns one Solver,
@@ -120,7 +123,11 @@ def cpu_run(inst, params, float_type, seconds, nthreads, rows=None):
 
     def work(t):
         from baryonyx_amd.util import pack_bits
-        s = O.Solver(inst, float_type=float_type, sort_mode=1, cost_norm=4, seed=1000 + t)
+        # sort_mode 0: calculator_sort with std::sort, as the reference runs it
+        # (itm-common.hpp:134-148); contract checks off: the reference's
+        # BARYONYX_FULL_OPTIMIZATION build (debug.hpp:103-111), its faster one
+        s = O.Solver(inst, float_type=float_type, sort_mode=CPU_SORT_MODE, cost_norm=4, seed=1000 + t)
+        s.set_contract_checks(False)
         delta = s.compute_delta(params.theta)
         bast = (inst.dense_costs() > 0) if inst.maximize else (inst.dense_costs() < 0)
         x0 = pack_bits(bast.astype(np.uint8))
@@ -173,8 +180,11 @@ def cpu_baseline(inst, params, float_type, seconds, threads):
         "cores": nthreads,
         "kind": "port",
         "one_thread_value": one,
-        "sample": f"oracle Solver per thread, restart-sweeps of the same instance: "
-                  f"{nthreads} threads x {ta:.1f}s = {na} row updates; 1 thread x {t1:.1f}s = {n1}",
+        "sample": f"oracle Solver per thread (sort_mode={CPU_SORT_MODE}: "
+                  f"{'std::sort as the reference' if CPU_SORT_MODE == 0 else 'canonical stable sort'}; "
+                  f"contract checks off = the reference's full-optimisation build), restart-sweeps of the "
+                  f"same instance: {nthreads} threads x {ta:.1f}s = {na} row updates; "
+                  f"1 thread x {t1:.1f}s = {n1}",
     }
 
 
@@ -414,8 +424,9 @@ class StdWorkload:
         self.batch = args.batch if args.batch > 0 else (256 if args.config == "c5" else 64)
         self.dev = _ffi.DeviceBatch(inst, cost, self.batch, float_type=float_type, device=local_rank)
         self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
-        for b in range(self.batch):  # one std engine per worker, distinct seeds
-            self.dev.set_rng(b, 1 + ((1 + rank) * 7919 + b * 104729) % 2147483645)
+        # one std engine per worker, distinct seeds (one transfer)
+        self.dev.set_rng_all(np.array([1 + ((1 + rank) * 7919 + b * 104729) % 2147483645
+                                       for b in range(self.batch)], np.uint32))
         self.scan_bytes = inst.nnz * 4 + inst.nnz / 8  # violated-row scan, per instance and sweep
         # the Bastert point (init_with_bastert, itm-common.hpp:255-283): x_j = 1 where
         # the cost pulls that way -- all zeros for a min-cost covering instance
@@ -585,36 +596,30 @@ def main():
     dev.kernel_time(reset=True)
     st0 = dev.status()
     # the exchange step of the restart pool: every T steps the ranks
-    # agree on the incumbent -- ONE allreduce(min) of the packed key (violated rows,
-    # objective, rank), then the winner's x in one masked allreduce, no host sync
-    # between the two (baryonyx_amd/dist.py) -- inside the timed region
-    incumbent = {"value": np.inf, "x": None, "exchanges": 0, "remaining": None}
-
-    def local_best():
-        st = dev.status()
-        best, best_b = np.inf, -1
-        for b in range(wl.batch):
-            if st["remaining"][b] == 0:
-                v = wl.objective(b)
-                if v < best:
-                    best, best_b = v, b
-        return best, best_b
+    # agree on the incumbent, inside the timed region.  bxh_incumbent finds the
+    # rank's best instance ON THE DEVICE (fewest violated rows, then the objective)
+    # and leaves its key, objective and x in a tensor; the collectives of
+    # baryonyx_amd/dist.py -- all-reduce(MIN) of the key's two words, then the
+    # winner's record in one masked all-reduce -- work on that tensor, and the
+    # carried incumbent stays on the device too: no read-back, no host loop.
+    from baryonyx_amd.dist import read_record, record_words, reduce_incumbent_device
+    maximize = bool(getattr(getattr(wl, "inst", None), "maximize", False))
+    dev.set_objective(wl.dense, float(getattr(getattr(wl, "inst", None), "obj_constant", 0.0)), maximize)
+    cdev = torch.device("cuda", local_rank)
+    loc = torch.zeros(record_words(dev.nwords), dtype=torch.int64, device=cdev)
+    incumbent = {"rec": None, "exchanges": 0}
 
     def exchange():
-        from baryonyx_amd.dist import reduce_incumbent
-        best, best_b = local_best()
-        remaining = 0
-        if incumbent["x"] is not None and incumbent["value"] <= best:
-            best, xw = incumbent["value"], incumbent["x"]
-        elif best_b >= 0:
-            xw = dev.get_x(best_b)
-        else:  # nothing feasible yet: offer the restart with the fewest violated rows
-            rem = np.asarray(dev.status()["remaining"])
-            worst_b = int(rem.argmin())
-            remaining, xw = int(rem[worst_b]), dev.get_x(worst_b)
-        val, xall, _ = reduce_incumbent(best, xw, device="cpu" if share else "cuda", remaining=remaining)
-        incumbent["value"], incumbent["x"] = val, xall
+        dev.incumbent(rank, record_device=loc.data_ptr() + dev.nwords * 8, x_device=loc.data_ptr(),
+                      read_back=False)
+        # (the gloo test rig -- ranks sharing one GPU -- reduces on the host)
+        incumbent["rec"] = reduce_incumbent_device(loc.cpu() if share else loc, carried=incumbent["rec"])
         incumbent["exchanges"] += 1
+
+    if world > 1:
+        exchange()  # untimed once: the kernels' first launch, the tensors' first use
+        incumbent = {"rec": None, "exchanges": 0}
+        barrier()
 
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -636,19 +641,16 @@ def main():
     dt_max = float(tmax.item())
     rows_all = float(rows_t.item())
 
-    # incumbent after the timed region: best feasible restart of this rank, then
-    # allreduce(min) of the objective and broadcast of the winner's x over RCCL
-    # (baryonyx_amd/dist.py)
-    best, best_b = np.inf, -1
-    for b in range(wl.batch):
-        if st1["remaining"][b] == 0:
-            v = wl.objective(b)
-            if v < best:
-                best, best_b = v, b
-    best_all = best
-    if world > 1:
-        exchange()
-        best_all = incumbent["value"]
+    # incumbent after the timed region: one more exchange (at world size 1 the same
+    # device search without collectives), ONE read-back of the winner's record, and its
+    # exact objective recomputed from x (the device sums in a tree: bxh_incumbent)
+    exchange()
+    _, xw_best, _, rem_best = read_record(incumbent["rec"])
+    best_all = np.inf
+    if rem_best == 0:
+        from baryonyx_amd.util import x_bits
+        best_all = float((wl.dense * x_bits(xw_best, dev.n).astype(np.float64)).sum()
+                         + float(getattr(getattr(wl, "inst", None), "obj_constant", 0.0)))
 
     if rank == 0:
         # algorithmic bytes: B(k) summed on the device over every

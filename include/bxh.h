@@ -306,6 +306,34 @@ int bxh_sweep(bxh_handle h, const bxh_sweep_args* args, bxh_status* status_batch
 int bxh_sweep_async(bxh_handle h, const bxh_sweep_args* args);
 int bxh_status_sync(bxh_handle h, bxh_status* status_batch);
 
+/* The incumbent of the batch, found on the device: the instance that
+ * best_solution_recorder would keep -- fewest violated rows (as the last sweep
+ * or bxh_order_init left them), then the better objective (`storage`'s order,
+ * lib/src/itm-optimizer-common.hpp:60-91, :147-190) -- for the exchange step of
+ * the restart pool.  bxh_set_objective uploads the ORIGINAL
+ * linear costs once (Cost::results sums those, itm-common.hpp:1044-1063).
+ * bxh_incumbent launches two small kernels on the handle's stream and leaves a
+ * 32-byte record and the winner's x ([nwords] bit_array blocks) in DEVICE memory:
+ * `record_device` / `x_device` when given (e.g. tensors the caller all-reduces
+ * over RCCL), the handle's own buffers otherwise.  `record_host` non-NULL: also
+ * synchronise and copy the record back -- the ONE read-back of an exchange.
+ * key_hi / key_lo: (violated rows << 44 | top 44 bits of the objective's ordered
+ * image), (its low 20 bits << 6 | rank) -- compared lexicographically, both
+ * non-negative; MIN names the best also when maximising.  The objective of an
+ * instance with violated rows counts as +inf (-inf when maximising).  `value`
+ * is summed in a fixed tree: exact for integer costs, within rounding of the
+ * reference's sequential sum otherwise. */
+typedef struct bxh_incumbent_record
+{
+    int64_t key_hi;
+    int64_t key_lo;
+    double value;
+    int32_t remaining;
+    int32_t instance;
+} bxh_incumbent_record;
+int bxh_set_objective(bxh_handle h, const double* cost_n, double constant, int maximize);
+int bxh_incumbent(bxh_handle h, int rank, void* record_device, void* x_device, bxh_incumbent_record* record_host);
+
 /* Device time of the sweep kernels launched through this handle, measured with
  * HIP events recorded on the launch stream around every kernel (the H2D copy
  * of kappa[] is outside the pair).  Synchronises the stream. */

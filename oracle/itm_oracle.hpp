@@ -33,6 +33,7 @@
 #define ORACLE_ITM_ORACLE_HPP
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -496,6 +497,10 @@ template<typename Float>
 struct ZSubSolvers; // oracle/itm_oracle_z.hpp
 
 // The Solver concept for the five solver kinds.
+// Row updates, over the whole process, behind which the reference's default
+// build would have failed its contract check (see Solver::contract_violations).
+inline std::atomic<std::uint64_t> g_contract_violations{ 0 };
+
 template<typename Float>
 struct Solver
 {
@@ -524,6 +529,17 @@ struct Solver
 
     std::uint64_t row_updates = 0; // metric counter
     std::uint64_t tie_rows = 0;    // rows whose sort met equal reduced costs
+
+    // The reference's working domain.  Behind every row update it checks
+    // `bx_expects(is_valid_constraint(slv, k, x))` (itm-common.hpp:464 for the
+    // 01 / 101 solvers, itm-solver-inequalities-Z.cpp:436 for Z), which ends
+    // the process (debug.hpp:45-63: std::terminate, or std::logic_error) unless
+    // the library is built with BARYONYX_FULL_OPTIMIZATION (debug.hpp:103-111).
+    // The restatement goes on, as that build does, and counts how often the
+    // default build would have stopped: a run with a count above zero is
+    // OUTSIDE what the reference can be asked about.
+    std::uint64_t contract_violations = 0;
+    bool check_contracts = true; // off: the full-optimisation build (no check, no count)
 
     Solver(random_engine& rng_,
            const Constraints& cs_,
@@ -836,12 +852,20 @@ struct Solver
             }
         }
 
-        if (kind == INEQZ)
-            return z_update_row(x, k, r_size, kappa, delta);
-
-        calculator_sort(R.data(), R.data() + r_size);
-        const int selected = select_variables(k, r_size, c_size);
-        return affect(x, k, selected, r_size, kappa, delta);
+        bool pi_changed;
+        if (kind == INEQZ) {
+            pi_changed = z_update_row(x, k, r_size, kappa, delta);
+        } else {
+            calculator_sort(R.data(), R.data() + r_size);
+            const int selected = select_variables(k, r_size, c_size);
+            pi_changed = affect(x, k, selected, r_size, kappa, delta);
+        }
+        // itm-common.hpp:464, itm-solver-inequalities-Z.cpp:436
+        if (check_contracts && !is_valid_constraint(k, x)) {
+            ++contract_violations;
+            g_contract_violations.fetch_add(1, std::memory_order_relaxed);
+        }
+        return pi_changed;
     }
 
     template<typename Iterator, typename GetK>
@@ -1205,6 +1229,7 @@ struct SolveResult
     RawResult best;
     std::uint64_t row_updates = 0;
     std::uint64_t sweeps = 0;
+    std::uint64_t contract_violations = 0; // Solver::contract_violations
 };
 
 // solver_functor::operator(), itm-solver-common.hpp:63-225.  `time_limit` is
@@ -1357,6 +1382,7 @@ solve(const Constraints& cs,
 
     r.has_solution_vector = !r.best.x.empty();
     r.row_updates = slv.row_updates;
+    r.contract_violations = slv.contract_violations;
     return r;
 }
 

@@ -433,6 +433,7 @@ struct OptimizeResult
     std::vector<unsigned> worker_rng;  // engine state of every worker at the end
     std::vector<long> worker_calls;    // optimize_functor::m_call_number
     std::uint64_t row_updates = 0;
+    std::uint64_t contract_violations = 0; // summed over the workers' solvers
     long rounds = 0;
     double sweep_seconds = 0.0; // CPU time inside compute.run / push_and_run, summed over the workers
 };
@@ -581,6 +582,7 @@ optimize(const Constraints& cs,
          long rounds)
 {
     OptimizeResult r;
+    const std::uint64_t contract_before = g_contract_violations.load();
     random_engine rng(p.seed);
     const int variables = cs.n;
     const Cost<Float> cost(obj, variables);
@@ -622,6 +624,7 @@ optimize(const Constraints& cs,
         r.row_updates += updates[i];
         r.sweep_seconds += seconds[i];
     }
+    r.contract_violations = g_contract_violations.load() - contract_before; // (one optimize at a time)
     return r;
 }
 

@@ -94,6 +94,8 @@ struct HandleBase
     virtual void set_rng(std::uint32_t s) = 0;
     virtual std::uint64_t row_updates() = 0;
     virtual std::uint64_t tie_rows() = 0;
+    virtual std::uint64_t contract_violations() = 0;
+    virtual void set_contract_checks(bool on) = 0;
     virtual double objective() = 0;
     virtual void order_init(int order) = 0;
     virtual int violated(std::int32_t* out) = 0;
@@ -229,6 +231,8 @@ struct Handle : HandleBase
     }
     std::uint64_t row_updates() override { return slv->row_updates; }
     std::uint64_t tie_rows() override { return slv->tie_rows; }
+    std::uint64_t contract_violations() override { return slv->contract_violations; }
+    void set_contract_checks(bool on) override { slv->check_contracts = on; }
     double objective() override { return original.results(x, obj.constant); }
     void order_init(int order) override
     {
@@ -455,6 +459,21 @@ orc_solver_tie_rows(void* h)
 {
     return H(h)->tie_rows();
 }
+uint64_t
+orc_solver_contract_violations(void* h)
+{
+    return H(h)->contract_violations();
+}
+uint64_t
+orc_contract_violations_total(void)
+{
+    return orc::g_contract_violations.load();
+}
+void
+orc_solver_set_contract_checks(void* h, int on)
+{
+    H(h)->set_contract_checks(on != 0);
+}
 double
 orc_solver_objective(void* h)
 {
@@ -518,6 +537,17 @@ orc_solve(const orc_problem* pb,
         orc::Objective obj;
         fill(cs, obj, pb);
         const orc::Params p = to_params(params);
+        if (cs.m == 0 || cs.n == 0) { // solve_problem's guard, itm-solver-common.hpp:269, :293-297
+            out->status = orc::ST_SUCCESS;
+            out->remaining_constraints = 0;
+            out->has_solution_vector = 0;
+            out->contract_violations = 0;
+            out->value = obj.constant;
+            out->loop = 0;
+            out->row_updates = 0;
+            out->sweeps = 0;
+            return 0;
+        }
         // init_random_generator_seed, itm-common.hpp:1442-1452 (seed > 0)
         orc::random_engine rng(p.seed);
         orc::SolveResult r =
@@ -531,6 +561,7 @@ orc_solve(const orc_problem* pb,
         out->loop = r.best.loop;
         out->row_updates = r.row_updates;
         out->sweeps = r.sweeps;
+        out->contract_violations = static_cast<int32_t>(std::min<std::uint64_t>(r.contract_violations, INT32_MAX));
         if (out_x_words && r.has_solution_vector)
             std::copy(r.best.x.w.begin(), r.best.x.w.end(), out_x_words);
         return 0;
@@ -564,6 +595,19 @@ orc_optimize(const orc_problem* pb,
         const orc::Params p = to_params(params);
         if (thread < 1 || rounds < 0 || p.seed == 0)
             throw std::invalid_argument("orc_optimize: thread >= 1, rounds >= 0, seed > 0");
+        if (cs.m == 0 || cs.n == 0) { // optimize_problem's guard, itm-optimizer-common.hpp:785-792
+            out->status = orc::ST_SUCCESS;
+            out->remaining_constraints = 0;
+            out->has_solution_vector = 0;
+            out->contract_violations = 0;
+            out->value = obj.constant;
+            out->loop = 0;
+            out->row_updates = 0;
+            out->sweeps = 0;
+            if (sweep_seconds)
+                *sweep_seconds = 0.0;
+            return 0; // (the population arrays are left as they came)
+        }
         const orc::OptimizeResult r =
           float_type == 0
             ? orc::optimize<float>(cs, obj, kind, maximize != 0, p, thread, static_cast<long>(rounds))
@@ -574,6 +618,7 @@ orc_optimize(const orc_problem* pb,
         out->value = r.population.front().value;
         out->loop = r.loop;
         out->row_updates = r.row_updates;
+        out->contract_violations = static_cast<int32_t>(std::min<std::uint64_t>(r.contract_violations, INT32_MAX));
         out->sweeps = static_cast<uint64_t>(r.rounds);
         if (sweep_seconds)
             *sweep_seconds = r.sweep_seconds;

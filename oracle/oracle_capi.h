@@ -55,7 +55,9 @@ typedef struct orc_result
     int32_t status;
     int32_t remaining_constraints;
     int32_t has_solution_vector;
-    int32_t pad_;
+    int32_t contract_violations; /* row updates behind which the reference's default build stops
+                                    (bx_expects(is_valid_constraint), itm-common.hpp:464,
+                                    itm-solver-inequalities-Z.cpp:436); saturates at INT32_MAX */
     double value;
     int64_t loop;
     uint64_t row_updates;
@@ -96,6 +98,16 @@ uint32_t orc_solver_get_rng(void* h);
 void orc_solver_set_rng(void* h, uint32_t state);
 uint64_t orc_solver_row_updates(void* h);
 uint64_t orc_solver_tie_rows(void* h); /* rows that met equal reduced costs */
+/* The reference's working domain: row updates of this solver behind which the
+ * reference's `bx_expects(is_valid_constraint(slv, k, x))` (itm-common.hpp:464,
+ * itm-solver-inequalities-Z.cpp:436) fails -- std::terminate in its default
+ * build, nothing in its BARYONYX_FULL_OPTIMIZATION build (debug.hpp:45-111).
+ * The oracle behaves as the latter and counts.  orc_contract_violations_total:
+ * the same over every solver, solve and optimize of the process. */
+uint64_t orc_solver_contract_violations(void* h);
+uint64_t orc_contract_violations_total(void);
+/* on = 0: skip the check (and the count), as the full-optimisation build does */
+void orc_solver_set_contract_checks(void* h, int on);
 double orc_solver_objective(void* h); /* Cost::results(x, constant) */
 
 /* compute_order::init / run / push_and_run */
@@ -117,7 +129,9 @@ int orc_solver_update_rows(void* h,
                            int is_push,
                            double obj_amp);
 
-/* whole solver_functor (itm-solver-common.hpp:63-225) */
+/* whole solver_functor (itm-solver-common.hpp:63-225) behind solve_problem's
+ * guard (:269-297): no merged constraint or no variable -> success, value =
+ * the objective's constant, no solution vector */
 int orc_solve(const orc_problem* pb,
               int kind,
               int float_type,

@@ -72,7 +72,7 @@ class OrcResult(C.Structure):
         ("status", C.c_int32),
         ("remaining_constraints", C.c_int32),
         ("has_solution_vector", C.c_int32),
-        ("pad_", C.c_int32),
+        ("contract_violations", C.c_int32),
         ("value", C.c_double),
         ("loop", C.c_int64),
         ("row_updates", C.c_uint64),
@@ -125,6 +125,12 @@ def lib():
         L.orc_solver_row_updates.restype = C.c_uint64
         L.orc_solver_tie_rows.argtypes = [C.c_void_p]
         L.orc_solver_tie_rows.restype = C.c_uint64
+        L.orc_solver_contract_violations.argtypes = [C.c_void_p]
+        L.orc_solver_contract_violations.restype = C.c_uint64
+        L.orc_contract_violations_total.argtypes = []
+        L.orc_contract_violations_total.restype = C.c_uint64
+        L.orc_solver_set_contract_checks.argtypes = [C.c_void_p, C.c_int]
+        L.orc_solver_set_contract_checks.restype = None
         L.orc_solver_objective.argtypes = [C.c_void_p]
         L.orc_solver_objective.restype = C.c_double
         L.orc_solver_order_init.argtypes = [C.c_void_p, C.c_int]
@@ -302,6 +308,19 @@ class Solver:
     def tie_rows(self):
         return self.L.orc_solver_tie_rows(self.h)
 
+    @property
+    def contract_violations(self):
+        """Row updates behind which the reference's default build would have
+        stopped (bx_expects(is_valid_constraint), itm-common.hpp:464,
+        itm-solver-inequalities-Z.cpp:436): above zero, the run is outside the
+        reference's working domain."""
+        return self.L.orc_solver_contract_violations(self.h)
+
+    def set_contract_checks(self, on):
+        """False: no check and no count (the reference's BARYONYX_FULL_OPTIMIZATION
+        build, debug.hpp:103-111) -- for timing."""
+        self.L.orc_solver_set_contract_checks(self.h, int(bool(on)))
+
     def objective(self):
         return self.L.orc_solver_objective(self.h)
 
@@ -328,6 +347,12 @@ class Solver:
         if r < 0:
             raise RuntimeError(self.L.orc_last_error().decode())
         return bool(r)
+
+
+def contract_violations_total():
+    """The process-wide count of Solver.contract_violations (every Solver, solve
+    and optimize so far)."""
+    return lib().orc_contract_violations_total()
 
 
 def solve(inst, float_type=1, params=None, kind=None, maximize=None):
