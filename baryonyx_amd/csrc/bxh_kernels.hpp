@@ -1429,6 +1429,10 @@ template<typename Float, bool PM1>
 __global__ __launch_bounds__(1024) void
 sweep_kernel(DevProblem pb, DevState st, DevSweep a)
 {
+#if defined(BXH_DEV_ONLY_NP) && !defined(BXH_DEV_KEEP_V1)
+    return; // (development builds of another kernel: see sweep_kernel_v2)
+#endif
+
     extern __shared__ __align__(16) unsigned char smem[];
     const int inst = blockIdx.x;
     if (a.active && !a.active[inst])
@@ -1798,10 +1802,12 @@ constexpr int Z_LDS_LIMIT = 160 * 1024; // the LDS of a gfx950 CU (bxh_device.hi
 // a table of the next ZW_TABLE rows of the list (scalars + conflict masks).
 constexpr int ZW_WAVES = 4;  // waves of the Z kernel's workgroup (256 threads)
 constexpr int ZW_TABLE = 64; // rows of the list staged in LDS at a time (== a wave: the group scan uses ballots)
+constexpr int ZW_CAP = 128;  // entries of a wave's row buffers: rows of up to ZW_RMAX elements go wave per row
+constexpr int ZW_RMAX = 127; // (a lane takes two elements of a row of more than 63)
 __host__ __device__ constexpr int
 zw_wave_bytes(int fsize)
 {
-    return 64 * (2 * fsize + 8 + 4 * 4);
+    return ZW_CAP * (2 * fsize + 8 + 4 * 4);
 }
 __host__ __device__ constexpr int
 zw_table_bytes()
@@ -1987,6 +1993,10 @@ template<typename Float, bool ZW>
 __global__ __launch_bounds__(256) void // (256 threads at most: the cached column slots want registers)
 sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
 {
+#if defined(BXH_DEV_ONLY_NP) && !defined(BXH_DEV_KEEP_Z)
+    return; // (development builds of another kernel: see sweep_kernel_v2)
+#endif
+
     extern __shared__ __align__(16) unsigned char smem[];
     const int inst = blockIdx.x;
     if (a.active && !a.active[inst])
@@ -2228,12 +2238,12 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
     int* const zflag = misc_s + MS_WAVES + 40; // [0..3] tie, [4..7] sub-solver wanted, [8..11] sel
     unsigned char* const zw_mine = zw_base + wave * zw_wave_bytes((int)sizeof(Float));
     auto w_val = [&](int w) { return (Float*)(zw_base + w * zw_wave_bytes((int)sizeof(Float))); };      // by element
-    auto w_vs = [&](int w) { return w_val(w) + 64; };                                                  // by position
-    auto w_key = [&](int w) { return (unsigned long long*)(w_val(w) + 128); };                         // by position
-    auto w_idp = [&](int w) { return (int*)(w_key(w) + 64); };                                         // element by position
-    auto w_fzp = [&](int w) { return w_idp(w) + 64; };                                                 // factor by position
-    auto w_pos = [&](int w) { return w_idp(w) + 128; };                                                // position by element
-    auto w_res = [&](int w) { return w_idp(w) + 192; };
+    auto w_vs = [&](int w) { return w_val(w) + ZW_CAP; };                                              // by position
+    auto w_key = [&](int w) { return (unsigned long long*)(w_val(w) + 2 * ZW_CAP); };                  // by position
+    auto w_idp = [&](int w) { return (int*)(w_key(w) + ZW_CAP); };                                     // element by position
+    auto w_fzp = [&](int w) { return w_idp(w) + ZW_CAP; };                                             // factor by position
+    auto w_pos = [&](int w) { return w_idp(w) + 2 * ZW_CAP; };                                         // position by element
+    auto w_res = [&](int w) { return w_idp(w) + 3 * ZW_CAP; };
     (void)zw_mine;
     int tbase = -0x40000000; // list position of table slot 0
     // inclusive prefix sum of an int over the wave (DPP: shifts inside a row of 16 lanes,
@@ -2293,12 +2303,12 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 __syncthreads();
                 // which of the three rows in front does a row clash with (shares a column,
                 // or too far apart in the matrix for the masks to tell), and is it a row a
-                // wave can take: at most 63 elements, a kind whose selection is the scan
+                // wave can take: at most ZW_RMAX elements, a kind whose selection is the scan
                 if (tid < ZW_TABLE) {
                     int cb = 0;
                     if (it + tid < nrows) {
                         const int rr = t_re[tid] - t_rs[tid];
-                        if (rr >= 1 && rr <= 63 && t_z[tid] >= Z_UNCONSTRAINED_BB)
+                        if (rr >= 1 && rr <= ZW_RMAX && t_z[tid] >= Z_UNCONSTRAINED_BB)
                             cb = 0x100;
                         const int k2 = t_k[tid];
                         for (int u = 1; u <= 3 && u <= tid; ++u) {
@@ -2501,7 +2511,187 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                 };
                 BXH_STAMP(9);
                 Float pik_old = 0, p_decayed = 0;
-                if (mine) {
+                // ---- rows of 64 .. ZW_RMAX elements (round 5): the lane takes element `lane` and
+                // element `lane + 64`, one after the other through the same cached column -- the
+                // first was loaded above, the second is loaded here; phase C reloads the one that
+                // is not in the registers.  Everything by position (vs, keys, ids, factors) is
+                // 128 entries long; the scan of select_variables runs twice with the running sum
+                // carried over.  Such rows are rare (21 of the 1000 of the telebus-shaped c5): the
+                // point is that they no longer leave the groups' loop for the one-row path.
+                const bool rlong = r > 63; // (wave-uniform)
+                Float l_val[2] = { 0, 0 }, l_pdec[2] = { 0, 0 }, l_cost[2] = { 0, 0 };
+                unsigned long long l_key[2] = { ~0ull, ~0ull };
+                int l_rank[2] = { 0, 0 }, l_fe[2] = { 0, 0 };
+                int4 l_desc[2] = { make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0) };
+                int l_cached = 0; // which of the lane's two elements the cached column belongs to
+                auto load_col = [&](int e) { // descriptor and the first 16 slots of element e's column
+                    c_desc = pb.zdesc[2 * e];
+                    const int4 d1 = pb.zdesc[2 * e + 1];
+                    fe = d1.x;
+                    if (sizeof(Float) == 8)
+                        c_cost = (Float)__hiloint2double(d1.z, d1.y);
+                    else
+                        c_cost = (Float)__int_as_float(d1.y);
+                    if (sizeof(Float) == 8) {
+                        const double2* pv = reinterpret_cast<const double2*>((const double*)P + c_desc.x);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const double2 t2 = pv[u];
+                            c_p[2 * u] = (Float)t2.x;
+                            c_p[2 * u + 1] = (Float)t2.y;
+                        }
+                    } else {
+                        const float4* pv = reinterpret_cast<const float4*>((const float*)P + c_desc.x);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 t4 = pv[u];
+                            c_p[4 * u] = (Float)t4.x;
+                            c_p[4 * u + 1] = (Float)t4.y;
+                            c_p[4 * u + 2] = (Float)t4.z;
+                            c_p[4 * u + 3] = (Float)t4.w;
+                        }
+                    }
+                    const uint4* rfv = reinterpret_cast<const uint4*>(pb.zcolp + c_desc.x);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        c_rp[u] = rfv[u];
+                    p_own_raw = P[c_desc.z];
+                };
+                auto fill_pi = [&]() { // c_f, c_pi = pi + P of the cached slots (own slot: set_own)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned w4[4] = { c_rp[u].x, c_rp[u].y, c_rp[u].z, c_rp[u].w };
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int rw_ = (int)(w4[t] & 0xffffu);
+                            c_pi[4 * u + t] = pi_s[rw_ < pb.m ? rw_ : 0];
+                            c_f[4 * u + t] = (Float)(int)(w4[t] >> 16);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        c_pi[u] = c_pi[u] + c_p[u];
+                };
+                auto form_val = [&](int h) { // reduced cost and key of the cached element -> l_*[h]
+                    fill_pi();
+                    const Float pk = pi_s[k];
+                    const Float pd = z_own() * theta; // decrease_preference (stored with affect's value)
+                    set_own(pd, pk);
+                    Float v = z_rc(pd, pk);
+                    if (push)
+                        v += obj_amp * c_cost;
+                    l_val[h] = v;
+                    l_key[h] = order_key<Float>(v, maximize);
+                    l_pdec[h] = pd;
+                    l_fe[h] = fe;
+                    l_desc[h] = c_desc;
+                    l_cost[h] = c_cost;
+                };
+                // select_variables for up to 127 positions: two passes of the ballot scan, lane t of
+                // pass h standing for i = t - 1 + 64 h, the running sum of the factors carried over
+                auto wave_select2 = [&]() -> int {
+                    unsigned long long valid[2], stops[2];
+                    int carry = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int i = lane - 1 + 64 * h;
+                        const bool in = i < r;
+                        const int S = wave_scan((i >= 0 && i < r) ? fzp_w[i] : 0) + carry;
+                        carry = __shfl(S, 63);
+                        const Float nv = i + 1 < r ? vs_w[i + 1] : (Float)0;
+                        valid[h] = __ballot(in && bkmin <= S && S <= bkmax);
+                        stops[h] = __ballot(in && i + 1 < r && (maximize ? nv < 0 : nv > 0));
+                    }
+                    if (!valid[0] && !valid[1])
+                        return -2;
+                    // (positions p = lane + 64 h, i = p - 1)
+                    const int fv = valid[0] ? __ffsll((long long)valid[0]) - 1 : 64 + __ffsll((long long)valid[1]) - 1;
+                    const unsigned long long after0 = fv < 64 ? stops[0] & ~((1ull << fv) - 1ull) : 0ull;
+                    const unsigned long long after1 = fv < 64 ? stops[1] : stops[1] & ~((1ull << (fv - 64)) - 1ull);
+                    const int leave = after0 ? __ffsll((long long)after0) - 1
+                                             : (after1 ? 64 + __ffsll((long long)after1) - 1 : r); // r: i = r - 1
+                    const unsigned long long upto0 = valid[0] & (leave >= 63 ? ~0ull : ((2ull << leave) - 1ull));
+                    const unsigned long long upto1 =
+                      leave < 64 ? 0ull : valid[1] & (leave - 64 >= 63 ? ~0ull : ((2ull << (leave - 64)) - 1ull));
+                    const int last = upto1 ? 64 + 63 - __clzll((long long)upto1) : 63 - __clzll((long long)upto0);
+                    return last - 1; // position -> i
+                };
+                if (mine && rlong) {
+                    const bool a1 = lane + 64 < r;
+                    form_val(0); // (every lane has an element `lane`: r >= 64)
+                    if (a1) {
+                        load_col(rs + lane + 64);
+                        form_val(1);
+                        l_cached = 1;
+                    }
+                    BXH_STAMP(10);
+                    key_w[lane] = l_key[0];
+                    key_w[lane + 64] = l_key[1]; // (~0 behind the row's last element: counts nowhere)
+                    __builtin_amdgcn_wave_barrier();
+                    const int r8 = (r + 7) & ~7;
+                    for (int j0 = 0; j0 < r8; j0 += 16) {
+                        ulonglong2 q[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            q[u] = reinterpret_cast<const ulonglong2*>(key_w + j0)[u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            l_rank[0] += q[u].x < l_key[0];
+                            l_rank[0] += q[u].y < l_key[0];
+                            l_rank[1] += q[u].x < l_key[1];
+                            l_rank[1] += q[u].y < l_key[1];
+                        }
+                    }
+                    idp_w[l_rank[0]] = lane;
+                    if (a1)
+                        idp_w[l_rank[1]] = lane + 64;
+                    __builtin_amdgcn_wave_barrier();
+                    const bool lost = idp_w[l_rank[0]] != lane || (a1 && idp_w[l_rank[1]] != lane + 64);
+                    tie = __ballot(lost) != 0ull;
+                    if (tie) {
+                        l_rank[0] = l_rank[1] = 0;
+                        for (int j0 = 0; j0 < r8; j0 += 8) {
+                            ulonglong2 q[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                q[u] = reinterpret_cast<const ulonglong2*>(key_w + j0)[u];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                l_rank[0] += (q[u].x < l_key[0]) || (q[u].x == l_key[0] && j0 + 2 * u < lane);
+                                l_rank[0] += (q[u].y < l_key[0]) || (q[u].y == l_key[0] && j0 + 2 * u + 1 < lane);
+                                l_rank[1] += (q[u].x < l_key[1]) || (q[u].x == l_key[1] && j0 + 2 * u < lane + 64);
+                                l_rank[1] += (q[u].y < l_key[1]) || (q[u].y == l_key[1] && j0 + 2 * u + 1 < lane + 64);
+                            }
+                        }
+                        idp_w[l_rank[0]] = lane;
+                        if (a1)
+                            idp_w[l_rank[1]] = lane + 64;
+                    }
+                    __builtin_amdgcn_wave_barrier(); // (every lane has read the keys by element)
+                    val_w[lane] = l_val[0];
+                    vs_w[l_rank[0]] = l_val[0];
+                    fzp_w[l_rank[0]] = l_fe[0];
+                    if (a1) {
+                        val_w[lane + 64] = l_val[1];
+                        vs_w[l_rank[1]] = l_val[1];
+                        fzp_w[l_rank[1]] = l_fe[1];
+                    }
+                    if (tie) {
+                        __builtin_amdgcn_wave_barrier();
+                        key_w[l_rank[0]] = l_key[0]; // by position: the runs the shuffle goes over
+                        if (a1)
+                            key_w[l_rank[1]] = l_key[1];
+                    } else {
+                        __builtin_amdgcn_wave_barrier();
+                        sel = wave_select2();
+                    }
+                    if (lane == 0) {
+                        zflag[wave] = tie ? 1 : 0;
+                        zflag[4 + wave] = tie ? 0 : sub_wanted(sel);
+                        zflag[8 + wave] = sel;
+                    }
+                }
+                if (mine && !rlong) {
                     if (lane < r) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) { // (padding: any finite pi; its factor is 0)
@@ -2609,7 +2799,25 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                                     }
                             }
                     __syncthreads();
-                    if (mine && tie) { // the new positions (values of a run are equal: vs stays)
+                    if (mine && tie && rlong) {
+                        const bool a1 = lane + 64 < r;
+                        pos_w[idp_w[lane]] = lane;
+                        if (a1)
+                            pos_w[idp_w[lane + 64]] = lane + 64;
+                        __builtin_amdgcn_wave_barrier();
+                        l_rank[0] = pos_w[lane];
+                        fzp_w[l_rank[0]] = l_fe[0];
+                        if (a1) {
+                            l_rank[1] = pos_w[lane + 64];
+                            fzp_w[l_rank[1]] = l_fe[1];
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        sel = wave_select2();
+                        if (lane == 0) {
+                            zflag[4 + wave] = sub_wanted(sel);
+                            zflag[8 + wave] = sel;
+                        }
+                    } else if (mine && tie) { // the new positions (values of a run are equal: vs stays)
                         if (lane < r)
                             pos_w[idp_w[lane]] = lane;
                         __builtin_amdgcn_wave_barrier();
@@ -2639,7 +2847,22 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                                 zflag[8 + w] = misc_s[MS_SEL];
                             __syncthreads();
                         }
-                    if (mine && zflag[4 + wave]) { // R's new order: positions, values, factors
+                    if (mine && zflag[4 + wave] && rlong) {
+                        const bool a1 = lane + 64 < r;
+                        sel = zflag[8 + wave];
+                        pos_w[idp_w[lane]] = lane;
+                        if (a1)
+                            pos_w[idp_w[lane + 64]] = lane + 64;
+                        __builtin_amdgcn_wave_barrier();
+                        l_rank[0] = pos_w[lane];
+                        vs_w[l_rank[0]] = l_val[0];
+                        fzp_w[l_rank[0]] = l_fe[0];
+                        if (a1) {
+                            l_rank[1] = pos_w[lane + 64];
+                            vs_w[l_rank[1]] = l_val[1];
+                            fzp_w[l_rank[1]] = l_fe[1];
+                        }
+                    } else if (mine && zflag[4 + wave]) { // R's new order: positions, values, factors
                         sel = zflag[8 + wave];
                         if (lane < r)
                             pos_w[idp_w[lane]] = lane;
@@ -2680,7 +2903,40 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                     }
                     BXH_STAMP(1);
                     const Float d = (kappa / (one - kappa)) + delta;
-                    if (lane < r) {
+                    if (rlong) {
+                        // the lane's two elements: the one whose column is in the registers first,
+                        // then the other (its column loaded again: nothing of it has changed but the
+                        // row's own entry, which set_own puts in)
+#pragma unroll
+                        for (int step = 0; step < 2; ++step) {
+                            const int hh = step == 0 ? l_cached : 1 - l_cached;
+                            if (lane + 64 * hh < r) {
+                                if (step == 1) {
+                                    load_col(rs + lane + 64 * hh);
+                                    fill_pi();
+                                }
+                                c_cost = l_cost[hh];
+                                const int j = c_desc.w;
+                                const int pe = c_desc.z;
+                                const bool up = sel < 0 ? false : (sel + 1 >= r ? true : l_rank[hh] <= sel);
+                                Float pp = up ? l_pdec[hh] + d : l_pdec[hh] - d;
+                                if (up)
+                                    atomicOr(&x_s[j >> 5], 1u << (j & 31));
+                                else
+                                    atomicAnd(&x_s[j >> 5], ~(1u << (j & 31)));
+                                set_own(pp, new_pi);
+                                const Float repair = z_rc(pp, new_pi);
+                                if (up) {
+                                    if (repair >= 0)
+                                        pp = pp - repair + d;
+                                } else {
+                                    if (repair <= 0)
+                                        pp = pp + repair - d;
+                                }
+                                P[pe] = pp;
+                            }
+                        }
+                    } else if (lane < r) {
                         const int j = c_desc.w;
                         const int pe = c_desc.z;
                         const bool up = sel < 0 ? false : (sel + 1 >= r ? true : rank <= sel);
@@ -2714,6 +2970,8 @@ sweep_kernel_z(DevProblem pb, DevState st, DevSweep a)
                         later = max(later, t_re[s0 + w] - t_rs[s0 + w]);
                     if (lane < r && lane >= later)
                         stale_s[lane] = vs_w[lane];
+                    if (lane + 64 < r && lane + 64 >= later)
+                        stale_s[lane + 64] = vs_w[lane + 64];
                 }
                 if (mine)
                     alg_w += t_rb[sl]; // (lane 0 of the wave counts; summed at the end)
@@ -3348,6 +3606,13 @@ __global__ __launch_bounds__(512) void
 sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
 {
     static_assert(!(MW && PIPE), "the pipelined sweep has one P array per instance");
+#ifdef BXH_DEV_ONLY_NP
+    // development builds (A/B libraries loaded with BXH_LIB, never the shipped one): only the
+    // fp64 01-solver forms with this piece count keep their bodies -- a build in a fraction of
+    // the time; every other form of this kernel returns at once
+    if (!(NP == BXH_DEV_ONLY_NP && sizeof(Float) == 8 && !PM1))
+        return;
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int LR = 2;
     const int NG = MW ? pb.groups : (PIPE ? pb.pipe : 1);
@@ -4981,12 +5246,16 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             int cN = 0, cZ = 0;
             bool flagged[2] = { false, false };
             unsigned f_old[2] = { 0u, 0u }, f_bits[2] = { 1u, 1u }; // (the filter's answers, read behind the reductions)
-            // Row chain: behind barrier 1 the staging waves issue the next row's late
-            // loads (twenty load instructions each), so the keys of the row go to the
-            // other waves first -- two entries per thread there, the staging waves take
-            // what is left (nothing at the scpnrh shape) and then skip the reductions.
+            // Row chain: one entry per thread over all eight waves (two where the row has more
+            // than 512 elements).  Behind barrier 1 the staging waves first issue the next row's
+            // late loads (twenty load instructions each, ~2 400 cycles) and the other waves the
+            // message, the record DMA and the row prefetches (~1 700); with the keys of the whole
+            // row on the other waves alone, two per thread (round 3), those reached barrier 2
+            // ~2 600 cycles behind the staging waves (profiles/r05/chain_timeline_r05.txt); split
+            // evenly the sweep is 0.8 % shorter (7.31 -> 7.25 ms).  -DBXH_KEYS_OTHER: the round-3
+            // placement.
             int ke[2] = { tid, tid + T };
-#ifndef BXH_KEYS_EVEN
+#ifdef BXH_KEYS_OTHER
             if (PIPE) {
                 const int STG = SW * 64, OTH = T - STG;
                 if (wave >= SW) {

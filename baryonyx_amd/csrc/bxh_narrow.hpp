@@ -233,6 +233,10 @@ template<typename Float, bool PM1, int W, int RPH, int OCC = 1>
 __global__ __launch_bounds__(64 * W, OCC) void
 sweep_kernel_narrow(DevProblem pb, DevState st, DevSweep a, NarrowParams np, NarrowRun run)
 {
+#if defined(BXH_DEV_ONLY_NP) && !defined(BXH_DEV_KEEP_NARROW)
+    return; // (development builds of another kernel: see sweep_kernel_v2)
+#endif
+
     extern __shared__ __align__(16) unsigned char smem[];
     const int inst = blockIdx.x;
     if (a.active && !a.active[inst])

@@ -56,6 +56,10 @@ template<typename Float, bool PM1>
 __global__ __launch_bounds__(256) void
 sweep_kernel_sw(DevProblem pb, DevState st, DevSweep a, NarrowRun run)
 {
+#if defined(BXH_DEV_ONLY_NP) && !defined(BXH_DEV_KEEP_SW)
+    return; // (development builds of another kernel: see sweep_kernel_v2)
+#endif
+
     extern __shared__ __align__(16) unsigned char smem[];
     const int inst = blockIdx.x;
     if (a.active && !a.active[inst])

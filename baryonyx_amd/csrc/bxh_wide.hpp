@@ -881,6 +881,10 @@ template<typename Float, bool PM1>
 __global__ __launch_bounds__(WIDE_T) void
 sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
 {
+#if defined(BXH_DEV_ONLY_NP) && !defined(BXH_DEV_KEEP_WIDE)
+    return; // (development builds of another kernel: see sweep_kernel_v2)
+#endif
+
     using Geo = WideGeom<Float>;
     extern __shared__ __align__(16) unsigned char smem[];
     const int G = wp.G;

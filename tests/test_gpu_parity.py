@@ -252,6 +252,16 @@ Z_WAVE_CASES = [
     ("z-wave-mixed-kinds", lambda: synth.make_zmix(80, 400, "int", 74, maxlen=14, maximize=True), 1, True, 0, 0.1),
     ("z-wave-mixed-kinds-min", lambda: synth.make_zmix(90, 500, "real", 75, maxlen=16, maximize=False), 1, False, 0, 0.3),
     ("z-wave-long-list", lambda: synth.make_z(400, 2500, 0.012, "int", 76), 1, False, 0, 0.0),
+    # rows of 64 .. 127 elements (round 5: two elements per lane of the wave that takes the row) next
+    # to short ones and to rows of 128 and more (the one-row path); integer costs tie, real ones do not
+    ("z-wave-two-per-lane", lambda: synth.make_z(90, 3000, 0.03, "int", 81), 1, False, 0, 0.0),
+    ("z-wave-two-per-lane-real", lambda: synth.make_z(80, 2400, 0.035, "real", 82), 1, True, 1, 0.2),
+    ("z-wave-two-per-lane-f32", lambda: synth.make_z(70, 2600, 0.04, "int", 83), 0, False, 2, 0.1),
+    ("z-wave-around-64", lambda: synth.make_z(120, 3200, 0.02, "int", 84), 1, True, 0, 0.3),
+    ("z-wave-around-128", lambda: synth.make_z(60, 3000, 0.041, "real", 85), 1, False, 0, 0.1),
+    # ... and with columns enough for such rows to share none: groups of long (and short) rows
+    ("z-wave-two-per-lane-groups", lambda: synth.make_z(100, 30000, 0.003, "int", 86), 1, False, 0, 0.0),
+    ("z-wave-two-per-lane-groups-real", lambda: synth.make_z(100, 24000, 0.0035, "real", 87), 1, True, 2, 0.2),
 ]
 
 
