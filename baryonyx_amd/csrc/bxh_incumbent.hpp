@@ -1,8 +1,8 @@
 // baryonyx_amd/csrc/bxh_incumbent.hpp -- the incumbent of a batch, found on the
 // device (bxh_incumbent, include/bxh.h): which instance holds the point
 // best_solution_recorder would keep (fewest violated rows, then the better
-// objective: `storage::insert`'s order, lib/src/itm-optimizer-common.hpp:147-190,
-// with raw_result's comparison :60-91), as one 32-byte record and the winner's
+// objective: `storage::sort`'s order, lib/src/itm-optimizer-common.hpp:424-442,
+// with raw_result_compare, lib/src/result.hpp:96-107), as one 32-byte record and the winner's
 // x, both left in device memory for the exchange step over RCCL
 // (baryonyx_amd/dist.py) -- no per-instance read-back, no host loop.
 #ifndef BXH_INCUMBENT_HPP
@@ -58,7 +58,7 @@ incumbent_pack(int remaining, double value, int rank, bool maximize, long long& 
     lo = static_cast<long long>((o & 0xFFFFFull) << kIncRankBits) | (rank & ((1 << kIncRankBits) - 1));
 }
 
-// value[b] = constant + sum_j cost[j] x_bj: Cost::results (itm-common.hpp:1044-1063,
+// value[b] = constant + sum_j cost[j] x_bj: Cost::results (itm-common.hpp:1140-1147,
 // the linear part) on the ORIGINAL costs.  One workgroup of 256 threads per
 // instance; thread t adds the set bits of the 32-bit words t, t + 256, ... in
 // rising j, the 256 partial sums are added in a fixed tree: deterministic, and

@@ -13,7 +13,7 @@ best_solution_recorder (lib/src/itm-optimizer-common.hpp:97-99, :804-857):
   in the count of violated rows or in the first 44 bits of the objective; a second
   all-reduce(MIN) of `lo`, in which only the ranks that tie in `hi` take part,
   makes the comparison EXACT in all 64 bits of the objective (storage::sort
-  compares exact values, itm-optimizer-common.hpp:60-91) and picks the lowest
+  compares exact values, itm-optimizer-common.hpp:424-442) and picks the lowest
   rank among equals;
 * the winner's x and its exact objective then travel in one more all-reduce in
   which only the winner contributes.

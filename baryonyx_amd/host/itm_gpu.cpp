@@ -574,6 +574,22 @@ struct device_pool
             ids.resize(static_cast<size_t>(workers));
         const bool own_costs = norm_costs.size() > 1;
         const int D = own_costs ? workers : static_cast<int>(ids.size());
+        if (own_costs) {
+            // One handle per worker = one copy of the matrix per worker (CSR, padded CSC,
+            // descriptors: ~64 bytes per element) beside its P (padded, ~1.2 elements).  Said
+            // up front, before the first of `workers` bxh_create calls, instead of an
+            // allocation failure somewhere in the middle of them: the devices are MI355X,
+            // 288 GB each.
+            double nnz = 0.0;
+            for (const auto& c : csts)
+                nnz += static_cast<double>(c.elements.size());
+            const double per_handle = nnz * (64.0 + 1.2 * sizeof(Float)) +
+                                      static_cast<double>(variables) * (8.0 + sizeof(Float)) +
+                                      static_cast<double>(csts.size()) * (32.0 + 2.0 * sizeof(Float));
+            const double per_device = per_handle * static_cast<double>((workers + ids.size() - 1) / ids.size());
+            if (per_device > 0.85 * 288.0e9)
+                throw solver_failure(solver_error_tag::not_enough_memory);
+        }
         for (int d = 0; d != D; ++d) {
             const int share = (workers - d + D - 1) / D; // workers d, d + D, ...
             dev.emplace_back(std::make_unique<device_batch>(

@@ -309,9 +309,9 @@ int bxh_status_sync(bxh_handle h, bxh_status* status_batch);
 /* The incumbent of the batch, found on the device: the instance that
  * best_solution_recorder would keep -- fewest violated rows (as the last sweep
  * or bxh_order_init left them), then the better objective (`storage`'s order,
- * lib/src/itm-optimizer-common.hpp:60-91, :147-190) -- for the exchange step of
+ * lib/src/itm-optimizer-common.hpp:424-442; raw_result_compare, lib/src/result.hpp:96-107) -- for the exchange step of
  * the restart pool.  bxh_set_objective uploads the ORIGINAL
- * linear costs once (Cost::results sums those, itm-common.hpp:1044-1063).
+ * linear costs once (Cost::results sums those, itm-common.hpp:1140-1147).
  * bxh_incumbent launches two small kernels on the handle's stream and leaves a
  * 32-byte record and the winner's x ([nwords] bit_array blocks) in DEVICE memory:
  * `record_device` / `x_device` when given (e.g. tensors the caller all-reduces

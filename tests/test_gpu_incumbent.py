@@ -1,6 +1,6 @@
 """-m gpu: bxh_incumbent -- the batch's best instance found on the device (fewest
 violated rows, then the objective: storage's order,
-lib/src/itm-optimizer-common.hpp:60-91, :147-190), its 32-byte record and the
+lib/src/itm-optimizer-common.hpp:424-442; raw_result_compare, lib/src/result.hpp:96-107), its 32-byte record and the
 winner's x left in device memory for the exchange step (baryonyx_amd/dist.py)."""
 import numpy as np
 import pytest

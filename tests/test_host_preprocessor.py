@@ -72,3 +72,15 @@ def test_split():  # preprocess.cpp:301-327
     r = H.preprocess(os.path.join(LP, "prepro.lp"), split=0)
     assert (r["split1"].variables, r["split1"].affected) == (0, 23)
     assert (r["split0"].variables, r["split0"].affected) == (0, 23)
+
+
+def test_capmo1_direct_unused_variable_goes_to_zero():
+    """lib/test/solve.cpp:197-240 depends on it: capmo1_direct.lp's bound line `t = 1`
+    is [0, 1] for the reference's reader (parser.cpp:944-956), t (cost +14 156 111) is
+    in no constraint, and the preprocessor leaves such a variable of a minimisation
+    at its lower bound -- nothing is added to the objective's constant.  (Rounds 1 - 4
+    read the line as t fixed at 1: constant 14 156 111, every value too large by it.)"""
+    r = H.preprocess(os.path.join(LP, "capmo1_direct.lp"))
+    assert r["info"].affected == 1
+    assert r["info"].objective_constant == 0.0
+    assert r["info"].variables == 10100
