@@ -4367,7 +4367,7 @@ sweep_kernel_v2(DevProblem pb, DevState st, DevSweep a)
             }
         };
         static_assert(NP <= 8, "one straight-line copy per piece count");
-        switch (npm_) { // wave-uniform
+        switch (__builtin_amdgcn_readfirstlane(npm_)) { // wave-uniform (said so: a scalar branch per case, no exec masks)
         case 1:
             run(std::integral_constant<int, 1>{});
             break;

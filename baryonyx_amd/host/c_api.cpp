@@ -211,6 +211,64 @@ bxc_parse(const char* path, bxc_problem_info* info)
     return 0;
 }
 
+// make_problem on a file, written out in a canonical text (tests compare it with an
+// independent restatement of the reference's reader, tests/lp_grammar_restatement.py:
+// canonical()).  Returns the reader's status; `needed` receives the text's length.
+BX_EXPORT int
+bxc_dump_problem(const char* path, char* out, int cap, int* needed)
+{
+    auto ctx = make_context(3);
+    const raw_problem pb = make_problem(ctx, path);
+    std::string t;
+    char line[256];
+    if (pb) {
+        std::snprintf(line, sizeof line, "type %d\nconstant %.17g", pb.type == objective_function_type::maximize ? 1 : 0,
+                      pb.objective.value);
+        t += line;
+        for (size_t i = 0; i != pb.vars.values.size(); ++i) {
+            t += "\nvar ";
+            t.append(pb.vars.names[i].data(), pb.vars.names[i].size());
+            std::snprintf(line, sizeof line, " %d %d %d", pb.vars.values[i].min, pb.vars.values[i].max,
+                          static_cast<int>(pb.vars.values[i].type));
+            t += line;
+        }
+        for (const auto& e : pb.objective.elements) {
+            std::snprintf(line, sizeof line, "\nobj %d %.17g", e.variable_index, e.factor);
+            t += line;
+        }
+        for (const auto& e : pb.objective.qelements) {
+            std::snprintf(line, sizeof line, "\nqobj %d %d %.17g", e.variable_index_a, e.variable_index_b, e.factor);
+            t += line;
+        }
+        const std::pair<const char*, const std::vector<constraint>*> kinds[] = {
+            { "eq", &pb.equal_constraints }, { "ge", &pb.greater_constraints }, { "le", &pb.less_constraints }
+        };
+        for (const auto& kv : kinds)
+            for (const auto& c : *kv.second) {
+                std::snprintf(line, sizeof line, "\n%s %d %d [", kv.first, c.id, c.value);
+                t += line;
+                t.append(c.label.data(), c.label.size());
+                t += "]";
+                bool first = true;
+                for (const auto& e : c.elements) {
+                    std::snprintf(line, sizeof line, "%s%d*%d", first ? " " : " ", e.factor, e.variable_index);
+                    t += line;
+                    first = false;
+                }
+                if (c.elements.empty())
+                    t += " ";
+            }
+    }
+    if (needed)
+        *needed = static_cast<int>(t.size());
+    if (out && cap > 0) {
+        const size_t n = std::min(t.size(), static_cast<size_t>(cap - 1));
+        std::memcpy(out, t.data(), n);
+        out[n] = '\0';
+    }
+    return static_cast<int>(pb.status);
+}
+
 // make_problem on a file; the variables' bounds and types as the reader left
 // them (min, max, variable_type), `cap` entries at most.  Returns the status.
 BX_EXPORT int

@@ -1,9 +1,14 @@
-// baryonyx_amd/host/lp_parser.cpp -- CPLEX-LP reader with the grammar the
-// reference accepts (lib/src/parser.cpp:1064-1257): objective sense, optional
-// label, linear terms and `[ ... ] / 2` quadratic terms, `subject to`
-// constraints `label: terms (<=|>=|=) rhs`, then `bounds`, `binary`,
-// `general`, `end`.  Variables are numbered by first appearance; repeated
-// variables inside one expression are accumulated.
+// baryonyx_amd/host/lp_parser.cpp -- the `.lp` reader, with the grammar the reference
+// accepts and its readings of it (lib/src/parser.cpp:268-1257): the tokens of
+// stream_buffer::next_token (:385-447), read_real (:565-611), a function element = [sign]
+// [number] [name] (:789-822), the `[ ... ] / 2` quadratic block (:692-786), `subject to`
+// constraints `[label:] elements op [sign] number` (:1115-1210), then `bounds` (:907-965),
+// `binary`, `general`, `end`.  Variables are numbered by first appearance; a variable named
+// twice in one function adds up.  Round 5: token for token the reference's (checked against
+// an independent Python restatement on every fixture and on generated texts,
+// tests/test_host_parser_grammar.py), quirks included -- a number token runs over `e` / `E`
+// (`3ex` is 3 times `x`), a second number in a row is a NAME, a constraint element without
+// a name names the empty variable, the operator of a bound line is not looked at.
 #include "private.hpp"
 
 #include <algorithm>
@@ -13,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <initializer_list>
+#include <iterator>
 #include <optional>
 #include <unordered_map>
 
@@ -29,72 +36,68 @@ ieq(std::string_view a, const char* b)
     return i == a.size() && b[i] == '\0';
 }
 
+// lib/src/parser.cpp:131-150 (is_separator)
 bool
 is_sep(char c)
 {
-    return c == '*' || c == '/' || c == '+' || c == '-' || c == '<' ||
-           c == '>' || c == '=' || c == ':' || c == '[' || c == ']' || c == '^';
+    return c == '<' || c == '=' || c == '>' || c == ':' || c == '-' || c == '+' || c == '[' ||
+           c == ']' || c == '*' || c == '^';
 }
 
 bool
-name_start(char c)
+number_char(char c) // :103-108 (is_number)
 {
-    return std::isalpha(static_cast<unsigned char>(c)) || c == '_' || c == '!' ||
-           c == '"' || c == '#' || c == '$' || c == '%' || c == '&' || c == '(' ||
-           c == ')' || c == ',' || c == ';' || c == '?' || c == '@' || c == '{' ||
-           c == '}' || c == '~' || c == '\'';
+    return (c >= '0' && c <= '9') || c == '.' || c == 'e' || c == 'E' || c == '-' || c == '+';
 }
 
-// Token stream: whitespace separated words, `\` comments, words split at
-// operator characters and between a leading number and a following name.
+// Token stream of stream_buffer::next_token (:385-447): words between white space; a word
+// that STARTS with a backslash drops the rest of its line; inside a word every separator is a
+// token of its own, and a token that starts with a digit, `.`, `-` or `+` ends in front of the
+// first character that is not one of 0-9 . e E - +.
 struct lexer
 {
     std::vector<std::string> tok;
     size_t pos = 0;
+    bool overlong = false; // a word beyond the reference's 512-byte token buffer
 
     explicit lexer(std::istream& is)
     {
-        std::string line;
-        while (std::getline(is, line)) {
-            size_t i = 0;
-            const size_t n = line.size();
-            while (i < n) {
-                const char c = line[i];
-                if (c == '\\')
-                    break;
-                if (std::isspace(static_cast<unsigned char>(c))) {
-                    ++i;
-                    continue;
-                }
-                if (is_sep(c)) {
-                    tok.emplace_back(1, c);
-                    ++i;
-                    continue;
-                }
-                size_t j = i;
-                if (std::isdigit(static_cast<unsigned char>(c)) || c == '.') {
-                    // number: digits [. digits] [e[+-]digits]
-                    while (j < n && (std::isdigit(static_cast<unsigned char>(line[j])) ||
-                                     line[j] == '.'))
-                        ++j;
-                    if (j < n && (line[j] == 'e' || line[j] == 'E')) {
-                        size_t k = j + 1;
-                        if (k < n && (line[k] == '+' || line[k] == '-'))
-                            ++k;
-                        if (k < n && std::isdigit(static_cast<unsigned char>(line[k]))) {
-                            while (k < n && std::isdigit(static_cast<unsigned char>(line[k])))
-                                ++k;
-                            j = k;
-                        }
-                    }
-                } else {
-                    while (j < n && !std::isspace(static_cast<unsigned char>(line[j])) &&
-                           !is_sep(line[j]) && line[j] != '\\')
-                        ++j;
-                }
-                tok.emplace_back(line.substr(i, j - i));
+        std::string text((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
+        const size_t n = text.size();
+        size_t i = 0;
+        auto space = [](char c) {
+            return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r';
+        };
+        while (i < n) {
+            while (i < n && space(text[i]))
+                ++i;
+            if (i >= n)
+                break;
+            size_t j = i;
+            while (j < n && !space(text[j]))
+                ++j;
+            if (text[i] == '\\') { // comment
+                while (j < n && text[j] != '\n')
+                    ++j;
                 i = j;
+                continue;
             }
+            if (j - i > 511)
+                overlong = true;
+            size_t cur = i;
+            while (cur < j) {
+                const char c0 = text[cur];
+                const bool num = (c0 >= '0' && c0 <= '9') || c0 == '.' || c0 == '-' || c0 == '+';
+                const size_t s0 = cur++;
+                if (is_sep(c0) || cur == j) {
+                    tok.emplace_back(1, c0);
+                    continue;
+                }
+                while (cur < j && !is_sep(text[cur]) && !(num && !number_char(text[cur])))
+                    ++cur;
+                tok.emplace_back(text.substr(s0, cur - s0));
+            }
+            i = j;
         }
     }
 
@@ -106,119 +109,6 @@ struct lexer
     void pop(size_t k = 1) { pos += k; }
     bool end() const { return pos >= tok.size(); }
 };
-
-bool
-is_number(std::string_view t)
-{
-    return !t.empty() &&
-           (std::isdigit(static_cast<unsigned char>(t[0])) || t[0] == '.');
-}
-
-bool
-is_name(std::string_view t)
-{
-    return !t.empty() && name_start(t[0]);
-}
-
-int
-keyword_len(const lexer& lx)
-{
-    const auto a = lx.peek(0), b = lx.peek(1);
-    auto colon = [&](size_t k) { return lx.peek(k) == ":" ? 1 : 0; };
-    if (ieq(a, "st") || ieq(a, "st.") || ieq(a, "s.t") || ieq(a, "s.t."))
-        return 1 + colon(1);
-    if ((ieq(a, "subject") && ieq(b, "to")) || (ieq(a, "sush") && ieq(b, "that")) ||
-        (ieq(a, "such") && ieq(b, "that")))
-        return 2 + colon(2);
-    if (ieq(a, "bounds") || ieq(a, "bound") || ieq(a, "binary") ||
-        ieq(a, "binaries") || ieq(a, "bin") || ieq(a, "general") ||
-        ieq(a, "generals") || ieq(a, "gen") || ieq(a, "end"))
-        return 1 + colon(1);
-    return 0;
-}
-
-struct term
-{
-    double factor;
-    std::string_view name; // empty: a constant
-};
-
-// [+|-] [number] [name]
-std::optional<term>
-read_term(lexer& lx)
-{
-    double sign = 1.0;
-    bool any = false;
-    while (lx.peek() == "+" || lx.peek() == "-") {
-        if (lx.peek() == "-")
-            sign = -sign;
-        lx.pop();
-        any = true;
-    }
-    double value = 1.0;
-    bool has_number = false;
-    if (is_number(lx.peek())) {
-        value = std::strtod(std::string(lx.peek()).c_str(), nullptr);
-        lx.pop();
-        has_number = true;
-    }
-    if (is_name(lx.peek()) && keyword_len(lx) == 0) {
-        term t{ sign * value, lx.peek() };
-        lx.pop();
-        return t;
-    }
-    if (has_number)
-        return term{ sign * value, std::string_view() };
-    (void)any;
-    return std::nullopt;
-}
-
-std::optional<operator_type>
-read_operator(lexer& lx)
-{
-    const auto a = lx.peek(0), b = lx.peek(1);
-    if (a == "<") {
-        lx.pop(b == "=" ? 2 : 1);
-        return operator_type::less;
-    }
-    if (a == ">") {
-        lx.pop(b == "=" ? 2 : 1);
-        return operator_type::greater;
-    }
-    if (a == "=") {
-        if (b == "<") {
-            lx.pop(2);
-            return operator_type::less;
-        }
-        if (b == ">") {
-            lx.pop(2);
-            return operator_type::greater;
-        }
-        lx.pop(b == "=" ? 2 : 1);
-        return operator_type::equal;
-    }
-    return std::nullopt;
-}
-
-std::optional<double>
-read_signed_number(lexer& lx)
-{
-    double sign = 1.0;
-    if (lx.peek() == "+" || lx.peek() == "-") {
-        if (lx.peek() == "-")
-            sign = -1.0;
-        lx.pop();
-    }
-    if (ieq(lx.peek(), "inf") || ieq(lx.peek(), "infinity")) {
-        lx.pop();
-        return sign * std::numeric_limits<double>::infinity();
-    }
-    if (!is_number(lx.peek()))
-        return std::nullopt;
-    const double v = std::strtod(std::string(lx.peek()).c_str(), nullptr);
-    lx.pop();
-    return sign * v;
-}
 
 struct builder
 {
@@ -459,12 +349,80 @@ struct seen_table
     }
 };
 
+// read_real(buf_1, buf_2), :587-611: [+|-] number -> {value, tokens read}; a sign without a
+// number is +-1 and one token, no sign and no number is 1 and NO token
+struct real_read
+{
+    double value;
+    int read;
+};
+
+real_read
+read_real2(std::string_view b1, std::string_view b2)
+{
+    if (b1 == "-") {
+        auto v = bound_real(b2);
+        return v ? real_read{ -1.0 * *v, 2 } : real_read{ -1.0, 1 };
+    }
+    if (b1 == "+") {
+        auto v = bound_real(b2);
+        return v ? real_read{ *v, 2 } : real_read{ 1.0, 1 };
+    }
+    auto v = bound_real(b1);
+    return v ? real_read{ *v, 1 } : real_read{ 1.0, 0 };
+}
+
+// read_function_element, :789-822: [sign] [number] [name]; the name is whatever token comes
+// next when it starts with a name character (digits are name characters: a second number in
+// a row is a name) and is no keyword
+struct element_read
+{
+    double factor;
+    std::string_view name;
+    int read;
+};
+
+std::optional<element_read>
+read_element(const lexer& lx)
+{
+    const real_read v = read_real2(lx.peek(0), lx.peek(1));
+    const std::string_view to_read = lx.peek(static_cast<size_t>(std::min(v.read, 2)));
+    if (!bound_keyword(to_read) && !to_read.empty() && bound_char_name(static_cast<unsigned char>(to_read[0]))) {
+        if (!bound_is_name(to_read))
+            return std::nullopt;
+        return element_read{ v.value, to_read, v.read + 1 };
+    }
+    return element_read{ v.value, std::string_view(), v.read };
+}
+
+// (the reference's buffer advances by 1 .. 9 tokens; anything else trips its contract check:
+// here the nearest error of the section being read)
+bool
+advance(lexer& lx, int read)
+{
+    if (read < 1 || read > 9)
+        return false;
+    lx.pop(static_cast<size_t>(read));
+    return true;
+}
+
+int
+section_len(const lexer& lx, std::initializer_list<const char*> words) // keyword [:] -> tokens, 0: not here
+{
+    for (auto w : words)
+        if (ieq(lx.peek(0), w))
+            return ieq(lx.peek(1), ":") ? 2 : 1;
+    return 0;
+}
+
 file_format_error_tag
 parse(lexer& lx, builder& b)
 {
     seen_table seen;
     int stamp_counter = 0; // 0: the objective, then one per constraint
     using tag = file_format_error_tag;
+    if (lx.overlong)
+        return tag::bad_name;
 
     if (ieq(lx.peek(), "maximize") || ieq(lx.peek(), "maximum") || ieq(lx.peek(), "max"))
         b.pb.type = objective_function_type::maximize;
@@ -474,68 +432,67 @@ parse(lexer& lx, builder& b)
         return tag::bad_objective_function_type;
     lx.pop();
 
-    if (keyword_len(lx) == 0 && lx.peek(1) == ":")
-        lx.pop(2); // objective label
+    if (!bound_keyword(lx.peek()) && ieq(lx.peek(1), ":"))
+        lx.pop(2); // objective label (:982-993)
 
-    // ---- objective ---------------------------------------------------------
-    while (!lx.end() && keyword_len(lx) == 0) {
+    // ---- objective (:1086-1113) ------------------------------------------------
+    while (!bound_keyword(lx.peek())) {
         const bool quad = lx.peek() == "[" ||
                           ((lx.peek() == "+" || lx.peek() == "-") && lx.peek(1) == "[");
-        if (quad) {
+        if (quad) { // (:692-786)
             double sign = 1.0;
             if (lx.peek() == "-")
                 sign = -1.0;
             if (lx.peek() != "[")
                 lx.pop();
             lx.pop(); // [
-            while (!lx.end() && lx.peek() != "]") {
-                auto t = read_term(lx);
-                if (!t || t->name.empty())
+            while (!lx.peek().empty() && lx.peek() != "]") {
+                const real_read v = read_real2(lx.peek(0), lx.peek(1));
+                const std::string_view name = lx.peek(static_cast<size_t>(std::min(v.read, 2)));
+                if (bound_keyword(name) || name.empty() || !bound_char_name(static_cast<unsigned char>(name[0])) ||
+                    !bound_is_name(name))
                     return tag::bad_objective_quadratic;
-                const int a = b.variable(t->name);
-                int c = -1;
+                lx.pop(static_cast<size_t>(v.read) + 1);
+                int a = -1, c = -1;
                 if (lx.peek() == "*") {
-                    if (!is_name(lx.peek(1)))
+                    if (!bound_is_name(lx.peek(1)))
                         return tag::bad_objective_quadratic;
+                    a = b.variable(name);
                     c = b.variable(lx.peek(1));
                     lx.pop(2);
-                } else if (lx.peek() == "^") {
-                    if (lx.peek(1) != "2")
-                        return tag::bad_objective_quadratic;
-                    c = a;
-                    lx.pop(2);
-                } else {
-                    return tag::bad_objective_quadratic;
-                }
+                } else if (lx.peek() == "^") { // (`^` is a separator: `^2` is always two tokens)
+                    lx.pop(lx.peek(1) == "2" ? 2 : 1);
+                    a = c = b.variable(name);
+                } else
+                    continue; // (neither: the element is dropped, as the reference drops it)
                 auto& q = b.pb.objective.qelements;
                 auto it = std::find_if(q.begin(), q.end(), [a, c](const auto& e) {
                     return (e.variable_index_a == a && e.variable_index_b == c) ||
                            (e.variable_index_a == c && e.variable_index_b == a);
                 });
                 if (it == q.end())
-                    q.emplace_back(t->factor * sign / 2.0, a, c);
+                    q.emplace_back(v.value * sign / 2.0, a, c);
                 else
-                    it->factor += t->factor * sign / 2.0;
+                    it->factor += v.value * sign / 2.0;
             }
-            if (lx.peek() != "]")
-                return tag::bad_objective_quadratic;
-            lx.pop();
+            lx.pop(); // ]
             if (lx.peek() == "/" && lx.peek(1) == "2")
                 lx.pop(2);
+            else if (lx.peek() == "/2")
+                lx.pop(1);
             else
                 return tag::bad_objective_quadratic;
             continue;
         }
-        auto t = read_term(lx);
+        auto t = read_element(lx);
         if (!t)
             return tag::bad_objective;
         if (t->name.empty()) {
             b.pb.objective.value += t->factor;
         } else {
-            // (a variable named twice adds up, lib/src/parser.cpp:1133-1141 -- found
-            // there by a scan of the elements read so far, O(r^2) per function; here by
-            // a stamp per variable: the set-covering files of 1e6 columns parse in
-            // linear time)
+            // (a variable named twice adds up, lib/src/parser.cpp:492-511 -- found there by a
+            // scan of the elements read so far, O(r^2) per function; here by a stamp per
+            // variable: the set-covering files of 1e6 columns parse in linear time)
             const int id = b.variable(t->name);
             auto& el = b.pb.objective.elements;
             const int pos = seen.find(id, 0);
@@ -545,48 +502,62 @@ parse(lexer& lx, builder& b)
             } else
                 el[static_cast<size_t>(pos)].factor += t->factor;
         }
+        if (!advance(lx, t->read))
+            return tag::bad_objective;
     }
 
-    // ---- constraints -------------------------------------------------------
+    // ---- constraints (:1115-1210) ----------------------------------------------
     {
-        const auto a = lx.peek();
-        const bool st = ieq(a, "st") || ieq(a, "st.") || ieq(a, "s.t") || ieq(a, "s.t.") ||
-                        ieq(a, "subject") || ieq(a, "sush") || ieq(a, "such");
+        int st = 0;
+        const auto a0 = lx.peek(0), a1 = lx.peek(1), a2 = lx.peek(2);
+        if (ieq(a0, "st") || ieq(a0, "st.") || ieq(a0, "s.t") || ieq(a0, "s.t."))
+            st = ieq(a1, ":") ? 2 : 1;
+        else if ((ieq(a0, "subject") && ieq(a1, "to")) || (ieq(a0, "sush") && ieq(a1, "that")))
+            st = ieq(a2, ":") ? 3 : 2;
         if (st) {
-            lx.pop(static_cast<size_t>(keyword_len(lx)));
+            lx.pop(static_cast<size_t>(st));
             int next_id = 0;
-            while (!lx.end() && keyword_len(lx) == 0) {
+            while (!lx.peek().empty() && !bound_keyword(lx.peek())) {
                 std::string_view label;
-                if (is_name(lx.peek()) && lx.peek(1) == ":") {
+                if (bound_char_name(static_cast<unsigned char>(lx.peek()[0])) && lx.peek(1) == ":") {
                     label = b.pb.strings->append(lx.peek());
                     lx.pop(2);
                 }
                 std::vector<function_element> elements;
                 const int stamp = ++stamp_counter;
                 bool first = true;
-                while (!lx.end() && lx.peek() != "<" && lx.peek() != ">" && lx.peek() != "=") {
-                    auto t = read_term(lx);
-                    if (!t || t->name.empty())
+                // (at least one element; then elements until a token starts with an operator
+                // character.  An element without a name names the EMPTY variable, :1143.)
+                while (first || (!lx.peek().empty() && !(lx.peek()[0] == '<' || lx.peek()[0] == '>' ||
+                                                         lx.peek()[0] == '='))) {
+                    auto t = read_element(lx);
+                    if (!t)
                         return tag::bad_constraint;
                     const int id = b.variable(t->name);
-                    const int pos = seen.find(id, stamp); // (:1159-1170, in linear time)
+                    const int pos = seen.find(id, stamp); // (:1146-1155, in linear time)
                     if (pos < 0) {
                         seen.mark(id, stamp, static_cast<int>(elements.size()));
-                        elements.emplace_back(static_cast<int>(t->factor), id);
+                        elements.emplace_back(to_int(t->factor), id);
                     } else
-                        elements[static_cast<size_t>(pos)].factor += static_cast<int>(t->factor);
+                        elements[static_cast<size_t>(pos)].factor += to_int(t->factor);
+                    if (!advance(lx, t->read))
+                        return tag::bad_constraint;
                     first = false;
                 }
-                if (first)
+                const int op_len = bound_operator(lx.peek(0), lx.peek(1));
+                if (!op_len)
                     return tag::bad_constraint;
-                auto op = read_operator(lx);
-                if (!op)
+                operator_type op = operator_type::equal;
+                if (lx.peek(0) == "<" || (lx.peek(0) == "=" && op_len == 2 && lx.peek(1) == "<"))
+                    op = operator_type::less;
+                else if (lx.peek(0) == ">" || (lx.peek(0) == "=" && op_len == 2 && lx.peek(1) == ">"))
+                    op = operator_type::greater;
+                lx.pop(static_cast<size_t>(op_len));
+                const real_read rhs = read_real2(lx.peek(0), lx.peek(1));
+                const int value = to_int(rhs.value);
+                if (!advance(lx, rhs.read))
                     return tag::bad_constraint;
-                auto rhs = read_signed_number(lx);
-                if (!rhs)
-                    return tag::bad_constraint;
-                const int value = static_cast<int>(*rhs);
-                switch (*op) {
+                switch (op) {
                 case operator_type::equal:
                     b.pb.equal_constraints.emplace_back(label, std::move(elements), value, next_id++);
                     break;
@@ -605,8 +576,8 @@ parse(lexer& lx, builder& b)
     // The reference's bound rules, token for token (lib/src/parser.cpp:1213-1226
     // around read_bound :907-965): the operators of a bound line are read and
     // ignored.
-    if (ieq(lx.peek(), "bounds") || ieq(lx.peek(), "bound")) {
-        lx.pop(static_cast<size_t>(keyword_len(lx)));
+    if (const int n = section_len(lx, { "bounds", "bound" })) {
+        lx.pop(static_cast<size_t>(n));
         while (!bound_keyword(lx.peek())) {
             auto bound = read_bound(lx);
             if (!bound)
@@ -620,10 +591,10 @@ parse(lexer& lx, builder& b)
         }
     }
 
-    // ---- binary / general ---------------------------------------------------
-    if (ieq(lx.peek(), "binary") || ieq(lx.peek(), "binaries") || ieq(lx.peek(), "bin")) {
-        lx.pop(static_cast<size_t>(keyword_len(lx)));
-        while (!lx.end() && keyword_len(lx) == 0) {
+    // ---- binary / general / end (:1228-1256) -------------------------------------
+    if (const int n = section_len(lx, { "binary", "binaries", "bin" })) {
+        lx.pop(static_cast<size_t>(n));
+        while (!bound_keyword(lx.peek())) {
             const int id = b.find(lx.peek());
             if (id < 0)
                 return tag::bad_binary;
@@ -631,9 +602,9 @@ parse(lexer& lx, builder& b)
             lx.pop();
         }
     }
-    if (ieq(lx.peek(), "general") || ieq(lx.peek(), "generals") || ieq(lx.peek(), "gen")) {
-        lx.pop(static_cast<size_t>(keyword_len(lx)));
-        while (!lx.end() && keyword_len(lx) == 0) {
+    if (const int n = section_len(lx, { "general", "generals", "gen" })) {
+        lx.pop(static_cast<size_t>(n));
+        while (!bound_keyword(lx.peek())) {
             const int id = b.find(lx.peek());
             if (id < 0)
                 return tag::bad_general;
@@ -641,9 +612,9 @@ parse(lexer& lx, builder& b)
             lx.pop();
         }
     }
-    if (ieq(lx.peek(), "end")) {
-        lx.pop(static_cast<size_t>(keyword_len(lx)));
-        return lx.end() ? tag::success : tag::bad_end_of_file;
+    if (const int n = section_len(lx, { "end" })) {
+        lx.pop(static_cast<size_t>(n));
+        return lx.peek().empty() ? tag::success : tag::bad_end_of_file;
     }
     return tag::bad_end;
 }

@@ -80,6 +80,7 @@ def lib():
         L.bxc_parse.argtypes = [C.c_char_p, C.POINTER(ProblemInfo)]
         ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
         L.bxc_variables.argtypes = [C.c_char_p, ip, ip, ip, C.c_int]
+        L.bxc_dump_problem.argtypes = [C.c_char_p, C.c_char_p, C.c_int, ip]
         L.bxc_merged.argtypes = [C.c_char_p, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, dp, dp, ip, ip,
                                  ip, ip, ip, dp]
         L.bxc_preprocess.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PreprocessInfo), C.c_int, C.c_int,
@@ -166,6 +167,17 @@ def parse(path) -> ProblemInfo:
     info = ProblemInfo()
     lib().bxc_parse(os.fsencode(path), C.byref(info))
     return info
+
+
+def dump(path):
+    """(status, canonical text) of make_problem on a file: type, constant, variables with
+    bounds and types, objective, quadratic terms, the three constraint lists."""
+    L = lib()
+    need = C.c_int()
+    st = L.bxc_dump_problem(os.fsencode(path), None, 0, C.byref(need))
+    buf = C.create_string_buffer(need.value + 1)
+    L.bxc_dump_problem(os.fsencode(path), buf, need.value + 1, C.byref(need))
+    return st, buf.value.decode("latin-1")
 
 
 def variables(path):
