@@ -2119,6 +2119,9 @@ bxh_create_device(const bxh_problem* pb,
     ds.rstale = h->rstale.p;
     ds.vlist = h->vlist.p;
     ds.vcount = h->vcount.p;
+    HIP_TRY(h->prof.alloc(B * 32)); // (diagnostic builds stamp phases here; zeros otherwise)
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    ds.prof = h->prof.p;
     ds.status = h->status.p;
     ds.vwork = h->vwork.p;
     ds.lcap = h->lcap;

@@ -31,6 +31,22 @@
 
 namespace bxh {
 
+// -DBXH_WPROF (diagnostic builds only, tools/debug/wprof_c4.py): shader-clock ticks of the phases
+// of a long tied row, accumulated by thread 0 of an instance's first workgroup in st.prof[inst][0..15]
+#ifdef BXH_WPROF
+#define BXH_WSTAMP(k_)                                                         \
+    do {                                                                       \
+        if (tid == 0 && grp == 0 && st.prof) {                                 \
+            const unsigned long long now_ = (unsigned long long)clock64();    \
+            st.prof[(size_t)inst * 32 + (k_)] += now_ - wprof_t;               \
+            wprof_t = now_;                                                    \
+        }                                                                      \
+    } while (0)
+#else
+#define BXH_WSTAMP(k_)                                                         \
+    do {                                                                       \
+    } while (0)
+#endif
 constexpr int WIDE_T = 512;      // threads of a workgroup
 constexpr int WIDE_TILE = 32;    // columns a wave streams together
 constexpr int WIDE_SMALL = 1024; // rows up to this length are sorted in LDS
@@ -350,6 +366,48 @@ wide_sort_coop(const unsigned long long* vbuf, int r, int n2, bool maximize, int
     // (the shared copies are written again by the next long row with a tie, behind
     // that row's own meeting: every workgroup has taken its copy by then)
     return true;
+}
+
+// std::shuffle(a, a + len, g) by ONE lane, g = minstd_rand0 in state `state`, for len <= 46340
+// (libstdc++'s two-swaps-per-draw branch, <bits/stl_algo.h>; uniform_int_distribution's
+// down-scaling with rejection, <bits/uniform_int_dist.h>): MinStd::shuffle in 32-bit
+// arithmetic -- every range here is below 2^31, and a 64-bit division costs a lane ten times a
+// 32-bit one.  Returns the engine's state behind the shuffle.
+__device__ inline unsigned
+lane_run_shuffle(int* a, unsigned len, unsigned state)
+{
+    if (len < 2)
+        return state;
+    auto draw = [&](unsigned urange) -> unsigned { // uniform_int_distribution{0, urange}(g)
+        const unsigned uerange = urange + 1u;
+        const unsigned scaling = 2147483645u / uerange;
+        const unsigned past = uerange * scaling;
+        unsigned ret;
+        do {
+            state = (unsigned)(((unsigned long long)state * 16807ull) % 2147483647ull);
+            ret = state - 1u;
+        } while (ret >= past);
+        return ret / scaling;
+    };
+    auto swp = [&](unsigned i, unsigned j) {
+        const int t = a[i];
+        a[i] = a[j];
+        a[j] = t;
+    };
+    unsigned i = 1;
+    if ((len % 2u) == 0u) {
+        swp(i, draw(1u));
+        ++i;
+    }
+    while (i != len) {
+        const unsigned b1 = i + 2u;
+        const unsigned x = draw((i + 1u) * b1 - 1u);
+        swp(i, x / b1);
+        ++i;
+        swp(i, x % b1);
+        ++i;
+    }
+    return state;
 }
 
 // std::shuffle of ONE run of equal keys (ids[0 .. L) in LDS) by all threads:
@@ -1707,6 +1765,9 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
             } else {
                 // ---- a long row: sorted in global scratch (every workgroup its
                 // own copy), tied runs shuffled by one thread ------------------
+#ifdef BXH_WPROF
+                unsigned long long wprof_t = (unsigned long long)clock64();
+#endif
                 const int n2 = next_pow2(r);
                 unsigned long long* const bkey0 = wp.bkey + (size_t)inst * (G + 2) * (size_t)wp.n2big;
                 int* const bid0 = wp.bid + (size_t)inst * (G + 2) * (size_t)wp.n2big;
@@ -1753,10 +1814,12 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                     else
                         bitonic_sort(bkey, bid, n2);
                 }
+                BXH_WSTAMP(0); // the sort
                 for (int i = tid; i + 1 < r; i += T)
                     if (bkey[i] == bkey[i + 1])
                         misc_s[MS_TIE] = 1;
                 __syncthreads();
+                BXH_WSTAMP(1); // tie detection
                 // ---- the tied runs.  Draw number g of the row's engine is a jump of the
                 // linear congruential engine, and a run of L elements takes L / 2 draws
                 // unless one is rejected: so every run's first draw is known from the run
@@ -1772,45 +1835,65 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                     const int RCAP = lp.union_bytes / 12;
                     int* rl_len = rl_head + RCAP;
                     int* rl_base = rl_len + RCAP;
-                    // ordered lists of the runs' first and last positions
+                    // ordered lists of the runs' first and last positions.  Every wave takes one
+                    // contiguous stretch of the row (whole 64-position steps: coalesced reads), counts
+                    // its heads and tails, and after ONE barrier writes them behind those of the waves
+                    // in front of it: two barriers per row (rounds 2 - 4: two per 512 positions and
+                    // pass, 160 for a row of 20 000 elements -- half of what a tied row cost on top).
                     int nh = 0, nt = 0;
-                    for (int pass = 0; pass < 2; ++pass) {
-                        int base = 0;
-                        for (int c0 = 0; c0 < r; c0 += T) {
-                            const int i = c0 + tid;
-                            bool f = false;
-                            if (i < r) {
+                    {
+                        const int NWv = T / 64;
+                        const int seg = (((r + NWv - 1) / NWv) + 63) & ~63;
+                        const int s0 = wave * seg, s1 = min(r, s0 + seg);
+                        auto flags = [&](int i, bool& fh, bool& ft) {
+                            fh = ft = false;
+                            if (i < s1) {
                                 const unsigned long long ki = bkey[i];
                                 const bool eq_next = i + 1 < r && bkey[i + 1] == ki;
                                 const bool eq_prev = i > 0 && bkey[i - 1] == ki;
-                                f = pass == 0 ? (eq_next && !eq_prev) : (eq_prev && !eq_next);
+                                fh = eq_next && !eq_prev;
+                                ft = eq_prev && !eq_next;
                             }
-                            const unsigned long long mask = __ballot(f);
-                            const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-                            if (lane == 0)
-                                misc_s[MS_WAVES + wave] = __popcll(mask);
-                            __syncthreads();
-                            int off = 0, tot = 0;
-                            for (int w = 0; w < T / 64; ++w) {
-                                const int cw = misc_s[MS_WAVES + w];
-                                if (w < wave)
-                                    off += cw;
-                                tot += cw;
-                            }
-                            if (f && base + off + prefix < RCAP) {
-                                if (pass == 0)
-                                    rl_head[base + off + prefix] = i;
-                                else
-                                    rl_len[base + off + prefix] = i; // (the last position, for now)
-                            }
-                            base += tot;
-                            __syncthreads();
+                        };
+                        int ch = 0, ct = 0;
+                        for (int c0 = s0; c0 < s1; c0 += 64) {
+                            bool fh, ft;
+                            flags(c0 + lane, fh, ft);
+                            ch += __popcll(__ballot(fh));
+                            ct += __popcll(__ballot(ft));
                         }
-                        if (pass == 0)
-                            nh = base;
-                        else
-                            nt = base;
+                        if (lane == 0) {
+                            misc_s[MS_WAVES + wave] = ch;
+                            misc_s[MS_WAVES + 16 + wave] = ct;
+                        }
+                        __syncthreads();
+                        int offh = 0, offt = 0;
+                        for (int w = 0; w < NWv; ++w) {
+                            const int cw = misc_s[MS_WAVES + w], tw = misc_s[MS_WAVES + 16 + w];
+                            if (w < wave) {
+                                offh += cw;
+                                offt += tw;
+                            }
+                            nh += cw;
+                            nt += tw;
+                        }
+                        for (int c0 = s0; c0 < s1; c0 += 64) {
+                            const int i = c0 + lane;
+                            bool fh, ft;
+                            flags(i, fh, ft);
+                            const unsigned long long mh = __ballot(fh), mt = __ballot(ft);
+                            const unsigned long long below = (1ull << lane) - 1ull;
+                            const int ph = offh + __popcll(mh & below), pt = offt + __popcll(mt & below);
+                            if (fh && ph < RCAP)
+                                rl_head[ph] = i;
+                            if (ft && pt < RCAP)
+                                rl_len[pt] = i; // (the last position, for now)
+                            offh += __popcll(mh);
+                            offt += __popcll(mt);
+                        }
+                        __syncthreads();
                     }
+                    BXH_WSTAMP(2); // the runs listed
                     const int nruns = nh;
                     (void)nt;
                     if (nruns <= RCAP) {
@@ -1859,58 +1942,27 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                             } else if (tid == 0)
                                 misc_s[WM_TAKE] = qb;
                             __syncthreads();
+                            BXH_WSTAMP(3); // every draw checked for a rejection
                             const int first_rej = misc_s[WM_TAKE];
-                            // the runs in front of it, side by side: one wave per run of up to 512
-                            const bool room = (T / 64) * 2 * 512 * 4 <= ring_bytes;
-                            if (room) {
-                                int* wsc = (int*)ring_s + wave * (2 * 512); // ids, partners
-                                for (int q = qb + wave; q < first_rej; q += T / 64) {
-                                    const int L = rl_len[q];
-                                    if (L > 512)
-                                        continue;
-                                    const int head = rl_head[q], bq = rl_base[q];
-                                    const bool even = (L & 1) == 0;
-                                    int* ids_w = wsc;
-                                    int* jt_w = wsc + 512;
-                                    for (int i = lane; i < L; i += 64) {
-                                        ids_w[i] = bid[head + i];
-                                        int jv = 0;
-                                        if (i >= 1) {
-                                            unsigned urange;
-                                            int d, half = 0;
-                                            unsigned b1 = 2;
-                                            if (even && i == 1) {
-                                                d = 0;
-                                                urange = 1u;
-                                            } else {
-                                                const int i0 = even ? (i & ~1) : (((i - 1) & ~1) + 1);
-                                                d = even ? (i >> 1) : ((i - 1) >> 1);
-                                                half = i - i0;
-                                                b1 = (unsigned)i0 + 2u;
-                                                urange = ((unsigned)i0 + 1u) * b1 - 1u;
-                                            }
-                                            const unsigned uerange = urange + 1u;
-                                            const unsigned scaling = 2147483645u / uerange;
-                                            const unsigned raw = lcg_jump(pb.lcg_pow, st_row, bq + d + 1) - 1u;
-                                            const unsigned xv = raw / scaling;
-                                            jv = (even && i == 1) ? (int)xv
-                                                                  : (half == 0 ? (int)(xv / b1) : (int)(xv % b1));
-                                        }
-                                        jt_w[i] = jv;
-                                    }
-                                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (one wave: LDS in order)
-                                    for (int p0 = lane; p0 < L; p0 += 64) {
-                                        int pos = p0;
-                                        for (int i = L - 1; i >= 1; --i) {
-                                            const int j = jt_w[i];
-                                            pos = pos == i ? j : (pos == j ? i : pos);
-                                        }
-                                        bid[head + p0] = ids_w[pos];
-                                    }
-                                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                }
+                            // the runs in front of it, side by side: one LANE per run of up to 512
+                            // elements (round 5).  No draw of these runs is rejected (checked above),
+                            // so run q starts at draw rl_base[q] of the row's engine, and its shuffle is
+                            // the serial std::shuffle on a private engine, in 32-bit arithmetic (all
+                            // ranges are below 2^31).  Rounds 2 - 4 gave every run a WAVE that traced
+                            // each final position back through all L swaps -- O(L^2 / 64) dependent LDS
+                            // reads per run: the 100 runs of ~200 equal costs of an integer-cost row of
+                            // 20 000 elements took ~270 us of its ~330 us of tie handling.  A lane per
+                            // run does L swaps in the workgroup's own copy of the ids (L2-resident),
+                            // all runs of the row at once.
+                            for (int q = qb + tid; q < first_rej; q += T) {
+                                const int L = rl_len[q];
+                                if (L > 512)
+                                    continue;
+                                lane_run_shuffle(bid + rl_head[q], (unsigned)L,
+                                                 lcg_jump(pb.lcg_pow, st_row, rl_base[q]));
                             }
                             __syncthreads();
+                            BXH_WSTAMP(4); // the short runs shuffled, a lane each
                             // the longer runs in front of it, one after the other
                             {
                                 int* ids_l = (int*)ring_s;
@@ -1919,7 +1971,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                                 int* out_l = jt_l + cap_run;
                                 for (int q = qb; q < first_rej; ++q) {
                                     const int L = rl_len[q];
-                                    if (room && L <= 512)
+                                    if (L <= 512)
                                         continue;
                                     const int head = rl_head[q];
                                     unsigned stq = lcg_jump(pb.lcg_pow, st_row, rl_base[q]);
@@ -1973,6 +2025,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                                 __syncthreads();
                             }
                         }
+                        BXH_WSTAMP(5); // long runs, runs behind a rejected draw
                         serial_head = r;
                         serial_state = st_row;
                     }
@@ -2084,6 +2137,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                     misc_s[MS_RNG] = (int)rng.s;
                 }
                 __syncthreads();
+                BXH_WSTAMP(6); // thread 0: what is left of the runs, the selection, pi and d
                 rng.s = (unsigned)misc_s[MS_RNG];
                 {
                     const int sel = misc_s[MS_SEL];

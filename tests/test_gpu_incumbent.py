@@ -84,3 +84,40 @@ def test_incumbent_needs_the_objective(bxh, oracle):
     with pytest.raises(bxh.BxhError):
         dev.incumbent()
     dev.close()
+
+
+def test_rccl_takes_the_collectives_of_the_exchange():
+    """The exchange step's three collectives (baryonyx_amd/dist.py) on RCCL itself: a process
+    group of ONE rank on the GPU -- every all-reduce is the identity, but the backend has to
+    accept the tensors as they are: int64 on the device, MIN and SUM.  (More ranks need more
+    GPUs than a test box has; the multi-rank logic runs on gloo, tests/test_dist_gloo.py.)"""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from baryonyx_amd.dist import make_record, read_record
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        rec = make_record(193.0, np.array([0xFFFFFFFFFFFFFFFF, 5], np.uint64), 0, 0, device="cuda")
+        n = rec.shape[0] - 4
+        hi = rec[n:n + 1].clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MIN)
+        lo = rec[n + 1:n + 2].clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        out = rec * ((rec[n:n + 1] == hi) & (rec[n + 1:n + 2] == lo)).to(torch.int64)
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        value, xw, owner, remaining = read_record(out)
+        assert (value, xw.tolist(), owner, remaining) == (193.0, [0xFFFFFFFFFFFFFFFF, 5], 0, 0)
+    finally:
+        dist.destroy_process_group()

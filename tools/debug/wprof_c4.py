@@ -1,0 +1,34 @@
+"""Diagnostic: where a long tied row of configs[3] (integer costs) spends its time in sweep_kernel_wide.
+Needs csrc/libbxh_wprof.so = a -DBXH_WPROF build (e.g. with -DBXH_DEV_ONLY_NP=5 -DBXH_DEV_KEEP_WIDE).
+    python tools/debug/wprof_c4.py [int|real] [steps]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ["BXH_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                                     "baryonyx_amd", "csrc", "libbxh_wprof.so")
+import numpy as np
+import torch
+import bench
+kind = sys.argv[1] if len(sys.argv) > 1 else "int"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+sys.argv = ["bench.py", "--config", "c4", "--cost-kind", kind]
+args = bench.parse()
+torch.cuda.set_device(0)
+wl = bench.XLWorkload(args, torch, 0, 0, 1)
+from baryonyx_amd import _ffi
+L = _ffi.lib()
+L.bxh_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+wl.step(0)
+t = np.zeros((wl.batch, 32), np.uint64)
+L.bxh_debug_profile(wl.dev.h, t.ctypes.data_as(C.POINTER(C.c_uint64)), 1)
+wl.dev.kernel_time(reset=True)
+for k in range(1, 1 + steps):
+    wl.step(k)
+ms, n = wl.dev.kernel_time()
+L.bxh_debug_profile(wl.dev.h, t.ctypes.data_as(C.POINTER(C.c_uint64)), 1)
+names = ["sort", "tie detection", "runs listed", "rejection pre-pass", "short runs (lane each)",
+         "long runs / behind a rejection", "thread 0: rest, selection, pi, d"]
+rows = steps * args.xl_sweep_rows
+print(f"kernel {ms / n:.2f} ms per launch, {rows} row updates per instance in {steps} launches")
+tot = t[:, :7].astype(np.float64).mean(axis=0)
+for nm, v in zip(names, tot):
+    print(f"  {nm:36s} {v / rows / 2400.0:8.2f} us per row update (2.4 GHz ticks)")
