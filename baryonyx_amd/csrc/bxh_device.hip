@@ -367,7 +367,8 @@ struct bxh_handle_s
     DevBuf<int2> col_desc;
     DevBuf<unsigned char> piw;
     DevBuf<unsigned long long> whash, wrec, vbuf, bkey;
-    DevBuf<unsigned> wcnt;
+    DevBuf<unsigned> wcnt, wcount;
+    DevBuf<int> wdl;
     DevBuf<int> bid, vflag32;
     bxh::WideParams wp{};
 
@@ -1663,6 +1664,10 @@ bxh_create(const bxh_problem* pb,
         HIP_TRY(h->vflag32.alloc(B * static_cast<size_t>(m)));
         if (batch <= 32 && !std::getenv("BXH_WIDE_OWN_SCAN"))
             HIP_TRY(h->xt.alloc(static_cast<size_t>(n)));
+        HIP_TRY(h->wcount.alloc(B * hs)); // zeros: no key has a duplicate, no tied key is listed
+        HIP_TRY(h->wdl.alloc(B * static_cast<size_t>(bxh::WIDE_TDL)));
+        HIP_TRY(hipMemsetAsync(h->wcount.p, 0, B * hs * sizeof(unsigned), h->own_stream));
+        HIP_TRY(hipMemsetAsync(h->wdl.p, 0, B * static_cast<size_t>(bxh::WIDE_TDL) * sizeof(int), h->own_stream));
         bxh::WideParams& wp = h->wp;
         wp.G = wide_g;
         wp.chmax = wide_chmax;
@@ -1681,7 +1686,13 @@ bxh_create(const bxh_problem* pb,
         wp.vflag32 = h->vflag32.p;
         wp.xt = h->xt.p;
         wp.skip_scan = h->xt.p ? 1 : 0;
-    wp.own_sort = std::getenv("BXH_WIDE_OWN_SORT") ? 1 : 0;
+        wp.own_sort = std::getenv("BXH_WIDE_OWN_SORT") ? 1 : 0;
+        wp.wcount = h->wcount.p;
+        wp.wdl = h->wdl.p;
+        {
+            const char* et = std::getenv("BXH_WIDE_TIEDFAST"); // "0": every tied row is sorted (tests, A/B)
+            wp.tied_fast = (et && et[0] == '0') ? 0 : 1;
+        }
     }
 
     HIP_TRY(set_lds_limits(device));
@@ -2059,6 +2070,10 @@ bxh_create_device(const bxh_problem* pb,
     HIP_TRY(h->wrec.alloc(B * Gz * 8));
     HIP_TRY(h->wcnt.alloc(4 * B + 1));
     HIP_TRY(hipMemsetAsync(h->wcnt.p, 0, (4 * B + 1) * sizeof(unsigned), s));
+    HIP_TRY(h->wcount.alloc(B * hs)); // zeros: no key has a duplicate, no tied key is listed
+    HIP_TRY(h->wdl.alloc(B * static_cast<size_t>(bxh::WIDE_TDL)));
+    HIP_TRY(hipMemsetAsync(h->wcount.p, 0, B * hs * sizeof(unsigned), s));
+    HIP_TRY(hipMemsetAsync(h->wdl.p, 0, B * static_cast<size_t>(bxh::WIDE_TDL) * sizeof(int), s));
     HIP_TRY(h->vbuf.alloc(B * static_cast<size_t>(rmax)));
     HIP_TRY(h->bkey.alloc(B * (Gz + 2) * n2big));
     HIP_TRY(h->bid.alloc(B * (Gz + 2) * n2big));
@@ -2087,6 +2102,12 @@ bxh_create_device(const bxh_problem* pb,
     wp.xt = h->xt.p;
     wp.skip_scan = h->xt.p ? 1 : 0;
     wp.own_sort = std::getenv("BXH_WIDE_OWN_SORT") ? 1 : 0;
+    wp.wcount = h->wcount.p;
+    wp.wdl = h->wdl.p;
+    {
+        const char* et = std::getenv("BXH_WIDE_TIEDFAST"); // "0": every tied row is sorted (tests, A/B)
+        wp.tied_fast = (et && et[0] == '0') ? 0 : 1;
+    }
     HIP_TRY(set_lds_limits(h->device));
 
     bxh::DevProblem& dp = h->dp;

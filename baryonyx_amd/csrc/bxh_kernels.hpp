@@ -303,6 +303,13 @@ struct MinStd
     template<typename Ptr>
     __device__ void shuffle(Ptr a, unsigned len)
     {
+        shuffle_inl(a, len);
+    }
+    // (the body, for callers that must not leave it to the compiler whether this becomes a call:
+    // sweep_kernel_wide, bxh_wide.hpp)
+    template<typename Ptr>
+    __device__ __attribute__((always_inline)) void shuffle_inl(Ptr a, unsigned len)
+    {
         if (len < 2)
             return;
         auto swp = [&](unsigned i, unsigned j) {

@@ -52,6 +52,9 @@ constexpr int WIDE_TILE = 32;    // columns a wave streams together
 constexpr int WIDE_SMALL = 1024; // rows up to this length are sorted in LDS
 constexpr int WIDE_LCG_POW = 32770; // entries of DevProblem::lcg_pow (bxh_create uploads that many)
 constexpr int WIDE_ISLOT = 80;   // bytes of an index slot (16 int32 + pad)
+constexpr int WIDE_TKEYS = 2048; // tied keys of a row the fast path takes (more: the row is sorted)
+constexpr int WIDE_TRUN = 1024;  // longest run the fast path splits at the selected position
+constexpr int WIDE_TDL = 64 + WIDE_TKEYS; // ints of WideParams::wdl per instance
 
 template<typename Float>
 struct WideGeom;
@@ -93,6 +96,10 @@ struct WideParams
     int own_sort;              // 1: a long tied row is sorted by every workgroup on its own (BXH_WIDE_OWN_SORT)
     int skip_scan;             // 1: the sweep kernel leaves compute_violated_constraints to
                                //    wide_flags_all_kernel (one pass over A for all instances)
+    unsigned* wcount;          // [batch][hmask+1] duplicates of the key in that slot of whash (0: none)
+    int* wdl;                  // [batch][WIDE_TDL] the row's tied keys: [0] how many, [1] flags,
+                               //    [8 + g] members of the split run in workgroup g, [64 + i] slot of tied key i
+    int tied_fast;             // 1: a tied row whose selection needs no sorted order takes the fast path
 };
 
 __host__ __device__ inline int
@@ -241,19 +248,35 @@ wide_sync(unsigned* cnt, unsigned target, unsigned* err, int* dead_s);
 // element's final position is its position in its own chunk plus, for every
 // other chunk -- staged in LDS in turn -- the number of pairs below it (a binary
 // search: the pairs are distinct), and it is written there (fkey / fid, shared).
-// Every workgroup then takes a copy of its own (okey / oid: the shuffle of the
-// tied runs permutes it).  Two meetings of the instance's workgroups at the
+// Every workgroup then takes a copy of the ids (oid: the shuffle of the tied runs
+// permutes it); the sorted keys stay where they are (fkey) and are read through L2.  Two meetings of the instance's workgroups at the
 // slow-row counter.  Returns false when a partner was lost.
 template<typename Float>
 __device__ inline bool
 wide_sort_coop(const unsigned long long* vbuf, int r, int n2, bool maximize, int grp, int G,
                unsigned long long* ckey, int* cid, unsigned long long* fkey, int* fid,
-               unsigned long long* okey, int* oid, unsigned long long* lk, int* li, int C,
-               unsigned* cnt_sl, unsigned& nslow, unsigned* err, int* dead_s)
+               int* oid, unsigned long long* lk, int* li, int C,
+               unsigned* cnt_sl, unsigned& nslow, unsigned* err, int* dead_s,
+               unsigned long long* wprof = nullptr)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     const int NC = n2 / C;
     constexpr int MAXU = 4; // C <= 4 * T
+#ifdef BXH_WPROF
+    unsigned long long wt_ = (unsigned long long)clock64();
+#define BXH_WSORT_STAMP(k_)                                                    \
+    do {                                                                       \
+        if (wprof) {                                                           \
+            const unsigned long long now_ = (unsigned long long)clock64();    \
+            wprof[(k_)] += now_ - wt_;                                         \
+            wt_ = now_;                                                        \
+        }                                                                      \
+    } while (0)
+#else
+#define BXH_WSORT_STAMP(k_)                                                    \
+    do {                                                                       \
+    } while (0)
+#endif
     auto ld64 = [](const unsigned long long* p_) -> unsigned long long {
         return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -288,7 +311,16 @@ wide_sort_coop(const unsigned long long* vbuf, int r, int n2, bool maximize, int
                         li[l] = ia;
                     }
                 }
-                __syncthreads();
+                // pair t = ... 64 w + lane works on the positions 128 w ... 128 w + 127 at every
+                // distance up to 64: the steps j = 64 ... 1 of a stage touch nothing another wave
+                // touches, and a wave's LDS accesses complete in order
+                if (j > 64 || j == 1)
+                    __syncthreads();
+                else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
             }
         for (int t = tid; t < C; t += T) {
             __hip_atomic_store(&ckey[c0 + t], lk[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -296,9 +328,11 @@ wide_sort_coop(const unsigned long long* vbuf, int r, int n2, bool maximize, int
         }
         __syncthreads();
     }
+    BXH_WSORT_STAMP(8); // own chunks sorted and published
     if (!wide_sync(cnt_sl, (unsigned)G * (nslow + 1u), err, dead_s))
         return false;
     ++nslow;
+    BXH_WSORT_STAMP(9); // first meeting
     // ---- final positions of the own chunks' pairs ---------------------------------
     for (int c = grp; c < NC; c += G) {
         const int c0 = c * C;
@@ -315,15 +349,17 @@ wide_sort_coop(const unsigned long long* vbuf, int r, int n2, bool maximize, int
                 mi[u] = ld32(&cid[c0 + t]);
             }
         }
+        // (chunk x holds the row-local ids x * C ... x * C + C - 1: all of them below this
+        // chunk's when x < c, all above when x > c -- so "pairs below (key, id)" is "keys <= key"
+        // in a chunk in front and "keys < key" in one behind: the search needs the keys only)
         for (int x = 0; x < NC; ++x) {
             if (x == c)
                 continue;
             __syncthreads(); // (the chunk staged before has been searched by every thread)
-            for (int t = tid; t < C; t += T) {
+            for (int t = tid; t < C; t += T)
                 lk[t] = ld64(&ckey[x * C + t]);
-                li[t] = ld32(&cid[x * C + t]);
-            }
             __syncthreads();
+            const bool front = x < c;
             int pos[MAXU];
 #pragma unroll
             for (int u = 0; u < MAXU; ++u)
@@ -331,18 +367,15 @@ wide_sort_coop(const unsigned long long* vbuf, int r, int n2, bool maximize, int
             for (int step = C >> 1; step > 0; step >>= 1) {
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
-                    const int q = pos[u] + step - 1;
-                    const unsigned long long kq = lk[q];
-                    const int iq = li[q];
-                    if (kq < mk[u] || (kq == mk[u] && iq < mi[u]))
+                    const unsigned long long kq = lk[pos[u] + step - 1];
+                    if (kq < mk[u] || (front && kq == mk[u]))
                         pos[u] += step;
                 }
             }
 #pragma unroll
             for (int u = 0; u < MAXU; ++u) {
                 const unsigned long long kq = lk[pos[u]];
-                const int iq = li[pos[u]];
-                if (kq < mk[u] || (kq == mk[u] && iq < mi[u]))
+                if (kq < mk[u] || (front && kq == mk[u]))
                     pos[u] += 1;
                 rank[u] += pos[u];
             }
@@ -354,17 +387,20 @@ wide_sort_coop(const unsigned long long* vbuf, int r, int n2, bool maximize, int
                 __hip_atomic_store(&fid[rank[u]], mi[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
     }
+    BXH_WSORT_STAMP(10); // final positions
     if (!wide_sync(cnt_sl, (unsigned)G * (nslow + 1u), err, dead_s))
         return false;
     ++nslow;
+    BXH_WSORT_STAMP(11); // second meeting
     // ---- a copy of the sorted row for this workgroup --------------------------------
-    for (int i = tid; i < n2; i += T) {
-        okey[i] = ld64(&fkey[i]);
+    // (the ids only, and the row's own r of them: the tied runs' shuffles permute them.  The keys
+    // are read where they are, through L2 -- the caller's bkey is fkey.  The shared arrays are
+    // written again by the next long row that is sorted, behind that sort's first meeting: every
+    // workgroup is through with this row by then)
+    for (int i = tid; i < r; i += T)
         oid[i] = ld32(&fid[i]);
-    }
     __syncthreads();
-    // (the shared copies are written again by the next long row with a tie, behind
-    // that row's own meeting: every workgroup has taken its copy by then)
+    BXH_WSORT_STAMP(12); // the copy
     return true;
 }
 
@@ -878,10 +914,12 @@ struct WideAsm<float>
 // 64-bit compare-and-swap per probe, executed at the memory side: coherent for
 // workgroups on any XCD).  Returns true when an equal key is already there.
 // *slot: where this key went (to clear it after the row), -1 if nowhere.
+// *dup: the slot that holds the equal key, -1 unless one was found.
 __device__ inline bool
-wide_hash_insert(unsigned long long* tab, unsigned mask, unsigned long long key, int* slot)
+wide_hash_insert(unsigned long long* tab, unsigned mask, unsigned long long key, int* slot, int* dup)
 {
     *slot = -1;
+    *dup = -1;
     if (key == 0ull) // (only a NaN maps to 0, the empty mark: let the sort path have the row)
         return true;
     unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 38) & mask;
@@ -891,11 +929,200 @@ wide_hash_insert(unsigned long long* tab, unsigned mask, unsigned long long key,
             *slot = (int)h;
             return false;
         }
-        if (old == key)
+        if (old == key) {
+            *dup = (int)h;
             return true;
+        }
         h = (h + 1) & mask;
     }
     return true; // table full (cannot happen: 4 slots per row entry)
+}
+
+// minstd_rand0's draws of std::shuffle over `len` elements (2 <= len <= 46 340: the pairwise
+// scheme) from `state`, without the swaps: the engine's state behind them.  See lane_run_shuffle.
+__device__ inline unsigned
+lane_run_dry(unsigned len, unsigned state)
+{
+    if (len < 2)
+        return state;
+    auto draw = [&](unsigned urange) {
+        const unsigned uerange = urange + 1u;
+        const unsigned scaling = 2147483645u / uerange;
+        const unsigned past = uerange * scaling;
+        unsigned ret;
+        do {
+            state = (unsigned)(((unsigned long long)state * 16807ull) % 2147483647ull);
+            ret = state - 1u;
+        } while (ret >= past);
+    };
+    unsigned i = 1;
+    if ((len % 2u) == 0u) {
+        draw(1u);
+        ++i;
+    }
+    while (i != len) {
+        draw((i + 1u) * (i + 2u) - 1u);
+        i += 2u;
+    }
+    return state;
+}
+
+// Bitwise OR of `v` over the workgroup (__syncthreads_or is the OR of predicates: one bit).
+// slot: a word of LDS scratch.  All threads, uniform.
+__device__ inline int
+wide_or_bits(int v, int* slot)
+{
+    if (threadIdx.x == 0)
+        *slot = 0;
+    __syncthreads();
+    if (v)
+        atomicOr(slot, v);
+    __syncthreads();
+    const int all = *slot;
+    __syncthreads(); // (every thread has read it: the word may be written again)
+    return all;
+}
+
+// slots of the workgroup's LDS scratch words (misc_s) beyond those of bxh_kernels.hpp (MS_*)
+enum
+{
+    WM_DEAD = 96, // a partner timed out: leave the sweep
+    WM_TNP = 97,  // longest column (in pieces) of this workgroup's part of the row
+    WM_TAKE = 100, // long tied row: where thread 0's serial shuffle takes over (a run beyond LDS)
+    WM_FLAG = 101  // ... a draw of a run's shuffle was rejected
+};
+
+// One round of "where do the shuffles of a row's tied runs stand": the runs qb ... nruns - 1
+// (lengths rl_len[], in key order) start at the engine state `st_row`, a run of L elements takes
+// L / 2 draws unless one is rejected.  rl_base[q] = draws in front of run q, counted from run
+// qb; *total = draws of all of them; returns the first run with a rejected draw (nruns: none),
+// or -1 when there are more draws than lcg_pow has powers (nothing is known then).  Draw g is
+// thread g % T's: its engine state follows from the one T draws earlier by a constant
+// multiplier.  A draw over a range of `uerange` values is rejected only above
+// 2147483645 - uerange: with no run beyond 512 elements (has_long false) one comparison
+// against the widest range clears all but one draw or so per row, and only those get the
+// search for their run, their own range and the division.  All threads, uniform; cand: 256
+// ints of LDS; misc_s: WM_TAKE, WM_FLAG, MS_WAVES + 32.
+__device__ inline int
+wide_first_rejection(const int* rl_len, int* rl_base, int qb, int nruns, bool has_long, unsigned st_row,
+                     const unsigned* lcg_pow, int* cand, int* misc_s, int* total)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) { // a running sum of the draws
+        int acc = 0;
+        for (int q0 = qb; q0 < nruns; q0 += 64) {
+            const int q = q0 + lane;
+            const int v = q < nruns ? (rl_len[q] >> 1) : 0;
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o)
+                    incl += up;
+            }
+            if (q < nruns)
+                rl_base[q] = acc + incl - v;
+            acc += __shfl(incl, 63);
+        }
+        if (lane == 0) {
+            misc_s[WM_TAKE] = nruns;   // first run with a rejected draw
+            misc_s[WM_FLAG] = acc;     // draws of the runs from qb on
+            misc_s[MS_WAVES + 32] = 0; // draws that need a closer look
+        }
+    }
+    __syncthreads();
+    const int total_draws = misc_s[WM_FLAG];
+    *total = total_draws;
+    if (total_draws + 1 >= WIDE_LCG_POW) {
+        __syncthreads(); // (misc_s may be written again)
+        return -1;
+    }
+    const unsigned aT = lcg_pow[T];
+    unsigned sg = tid < total_draws ? lcg_jump(lcg_pow, st_row, tid + 1) : 1u;
+    constexpr int CAND = 256;
+    const unsigned widest = has_long ? 2147483645u : 513u * 514u;
+    for (int g = tid; g < total_draws; g += T) {
+        if (sg - 1u > 2147483645u - widest) {
+            const int slot = atomicAdd(&misc_s[MS_WAVES + 32], 1);
+            if (slot < CAND)
+                cand[slot] = g;
+        }
+        unsigned long long x = (unsigned long long)aT * sg;
+        x = (x & 0x7fffffffull) + (x >> 31);
+        x = (x & 0x7fffffffull) + (x >> 31);
+        sg = (unsigned)(x >= 0x7fffffffull ? x - 0x7fffffffull : x);
+    }
+    __syncthreads();
+    const int ncand = misc_s[MS_WAVES + 32];
+    const bool all = ncand > CAND; // (too many to list: every draw closely)
+    for (int e = tid; e < (all ? total_draws : ncand); e += T) {
+        const int g = all ? e : cand[e];
+        int lo = qb, hi = nruns - 1; // last run whose first draw is <= g
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (rl_base[mid] <= g)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const int q = lo;
+        const int L = rl_len[q], d = g - rl_base[q];
+        const bool even = (L & 1) == 0;
+        unsigned urange;
+        if (even && d == 0)
+            urange = 1u;
+        else {
+            const unsigned i0 = even ? 2u * (unsigned)d : 2u * (unsigned)d + 1u;
+            urange = (i0 + 1u) * (i0 + 2u) - 1u;
+        }
+        const unsigned uerange = urange + 1u;
+        const unsigned raw = lcg_jump(lcg_pow, st_row, g + 1) - 1u;
+        const unsigned scaling = 2147483645u / uerange;
+        if (raw >= uerange * scaling)
+            atomicMin(&misc_s[WM_TAKE], q);
+    }
+    __syncthreads();
+    const int first_rej = misc_s[WM_TAKE];
+    __syncthreads(); // (every thread has read it: misc_s may be written again)
+    return first_rej;
+}
+
+// The engine's way through the shuffles of a row's tied runs when only their lengths are known
+// (rl_len[0 .. nruns), in key order, none beyond 46 340): rl_state[q] = the state in front of
+// run q, *state_out = the state behind the last.  False when it cannot be told (see above).
+__device__ inline bool
+wide_runs_dry(const int* rl_len, int* rl_base, unsigned* rl_state, int nruns, bool has_long, unsigned st0,
+              const unsigned* lcg_pow, int* cand, int* misc_s, unsigned* state_out)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    int qb = 0;
+    unsigned st_row = st0;
+    while (qb < nruns) {
+        int total_draws = 0;
+        const int first_rej =
+          wide_first_rejection(rl_len, rl_base, qb, nruns, has_long, st_row, lcg_pow, cand, misc_s, &total_draws);
+        if (first_rej < 0)
+            return false;
+        for (int q = qb + tid; q < nruns && q <= first_rej; q += T)
+            rl_state[q] = lcg_jump(lcg_pow, st_row, rl_base[q]);
+        if (first_rej >= nruns) {
+            st_row = lcg_jump(lcg_pow, st_row, total_draws);
+            qb = nruns;
+        } else {
+            // the run with the rejected draw: its draws one by one
+            if (tid == 0)
+                misc_s[MS_RNG] = (int)lane_run_dry((unsigned)rl_len[first_rej],
+                                                   lcg_jump(lcg_pow, st_row, rl_base[first_rej]));
+            __syncthreads();
+            st_row = (unsigned)misc_s[MS_RNG];
+            qb = first_rej + 1;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    *state_out = st_row;
+    return true;
 }
 
 // Arrival of this workgroup at one of the instance's counters and wait for
@@ -924,14 +1151,6 @@ wide_sync(unsigned* cnt, unsigned target, unsigned* err, int* dead_s)
     __syncthreads();
     return *dead_s == 0;
 }
-
-enum
-{
-    WM_DEAD = 96, // a partner timed out: leave the sweep
-    WM_TNP = 97,  // longest column (in pieces) of this workgroup's part of the row
-    WM_TAKE = 100, // long tied row: where thread 0's serial shuffle takes over (a run beyond LDS)
-    WM_FLAG = 101  // ... a draw of a run's shuffle was rejected
-};
 
 // One sweep of every instance: compute_order::run / push_and_run
 // (itm-common.hpp:682-880) for the orders none / reversing / random_sorting.
@@ -991,6 +1210,8 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
     unsigned* xg = st.x + (size_t)inst * (2 * pb.nwords);
     Float* staleg = (Float*)st.rstale + (size_t)inst * (pb.rmax + 1);
     unsigned long long* htab = wp.whash + (size_t)inst * ((size_t)wp.hmask + 1);
+    unsigned* hcount = wp.wcount + (size_t)inst * ((size_t)wp.hmask + 1);
+    int* tdl = wp.wdl + (size_t)inst * WIDE_TDL;
     unsigned long long* recg = wp.wrec + (size_t)inst * G * 8;
     unsigned long long* vbuf = wp.vbuf + (size_t)inst * pb.rmax;
     unsigned* cnt_s1 = wp.wcnt + (size_t)inst * 4;
@@ -1033,7 +1254,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
     __syncthreads();
     if (tid == 0) {
         if (ord == 2) // random_sorting (itm-common.hpp:708-714 / :817-823), every copy alike
-            rng.shuffle(vrows, (unsigned)nrows);
+            rng.shuffle_inl(vrows, (unsigned)nrows);
         misc_s[MS_RNG] = (int)rng.s;
     }
     __syncthreads();
@@ -1353,6 +1574,8 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
         }
         if (tid < 80)
             part_s[tid] = (tid == 66 || tid == 69) ? ~0ull : 0ull;
+        if (tid == 0)
+            misc_s[MS_WAVES + 34] = 0; // tied keys this workgroup lists
         __syncthreads();
 
         // ---- this workgroup's record of the row ----------------------------
@@ -1363,9 +1586,21 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
             bool tie = false;
             for (int l = tid; l < cnt; l += T) {
                 const unsigned long long key = order_key<Float>(val_s[l], maximize);
-                int slot;
-                tie |= wide_hash_insert(htab, wp.hmask, key, &slot);
+                int slot, dup;
+                tie |= wide_hash_insert(htab, wp.hmask, key, &slot, &dup);
                 hslot_s[l] = slot;
+                if (wp.tied_fast) {
+                    // the duplicates of a key are counted where the key sits, and the first of
+                    // them lists the key: what a tied row needs instead of its sorted order
+                    // (listed in LDS first -- the staging slots are idle -- and then with ONE
+                    // addition per workgroup to the instance's counter: a thousand additions to one
+                    // address cost a tied row more than everything else here)
+                    if (dup >= 0) {
+                        if (atomicAdd(&hcount[dup], 1u) == 0u)
+                            ((int*)uni)[atomicAdd(&misc_s[MS_WAVES + 34], 1)] = dup;
+                    } else if (slot < 0)
+                        atomicOr(&tdl[1], 1); // (a NaN: the row is sorted)
+                }
                 if (key < A) {
                     A2 = A;
                     A = key;
@@ -1400,6 +1635,17 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
             }
         }
         __syncthreads();
+        if (wp.tied_fast && misc_s[MS_WAVES + 34] > 0) {
+            const int nloc = misc_s[MS_WAVES + 34];
+            if (tid == 0)
+                misc_s[MS_WAVES + 35] = atomicAdd(&tdl[0], nloc);
+            __syncthreads();
+            const int at0 = misc_s[MS_WAVES + 35];
+            for (int i = tid; i < nloc; i += T)
+                if (at0 + i < WIDE_TKEYS)
+                    __hip_atomic_store(&tdl[64 + at0 + i], ((const int*)uni)[i], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (tid < 8) {
             unsigned long long v;
             const unsigned long long a1 = part_s[69];
@@ -1435,12 +1681,39 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
         __syncthreads();
 
         // ---- selection without sorting: the same scalar code in every thread
-        // of every workgroup (see sweep_kernel_v2) ----------------------------
+        // of every workgroup (see sweep_kernel_v2).  A row with equal reduced costs
+        // takes it too (round 5) when the tie table tells all that the sorted order
+        // would be used for: calculator_sort shuffles every run of equal values
+        // (itm-common.hpp:139-147), which moves the engine by draws that follow from the
+        // run LENGTHS in key order alone, and the order inside a run only matters for the
+        // one run that the selected position splits.  The tied keys and their counts
+        // (a few hundred in a row of 20 000 integer-cost columns) come out of the table,
+        // are put in order in LDS, the engine is taken through the runs without a swap
+        // (wide_runs_dry), and the split run -- if there is one -- is shuffled for real:
+        // its members are told apart by their ordinal in the row (a count per workgroup,
+        // one more meeting).  Anything else (a selected position whose key the records
+        // do not give, more than WIDE_TKEYS tied keys, a run beyond 46 340) is sorted.
         bool fast = false;
         int f_mode = 0, f_nN = 0, f_nZ = 0;
         unsigned long long f_thr = 0ull;
         Float f_d = 0, f_newpi = 0;
         bool f_pich = false;
+        bool row_tied = false;
+        bool f_split = false; // the run of f_thr goes on behind the selected position
+        int f_split_q = 0, f_split_off = 0, f_split_len = 0;
+        // LDS of the tied keys: the staging slots (idle outside the column sums), 256 ints of the pi window
+        int tk_cap = min(WIDE_TKEYS, (lp.union_bytes - 8 * WIDE_TRUN - 4 * wp.chmax) / 20);
+        tk_cap = tk_cap >= 64 && wp.ring * (int)sizeof(Float) >= 1024 ? next_pow2(tk_cap + 1) / 2 : 0; // a power of two
+        unsigned long long* tk_key = (unsigned long long*)uni;            // [tk_cap] in key order
+        int* tk_len = (int*)(uni + (size_t)tk_cap * 8);                   // [tk_cap] elements of the run
+        int* tk_base = tk_len + tk_cap;                                   // [tk_cap] (wide_first_rejection)
+        unsigned* tk_state = (unsigned*)(tk_base + tk_cap);               // [tk_cap] engine in front of the run
+        int* tk_list = (int*)(tk_state + tk_cap);                         // [WIDE_TRUN] the split run, shuffled
+        int* tk_inv = tk_list + WIDE_TRUN;                                // [WIDE_TRUN] position of a member
+        int* tk_ord = tk_inv + WIDE_TRUN;                                 // [chmax] ordinal of an own member
+        int* tk_cand = (int*)ring_s;                                      // [256]
+        for (int g = 0; g < G; ++g)
+            row_tied |= rec_s[g * 8 + 6] != 0ull; // (a row of one NaN counts: its flag is to be taken back)
         if (r >= 2) {
             unsigned long long g1 = ~0ull, gx = 0ull, gxN = 0ull, gnS = ~0ull;
             int nN = 0, nZ = 0;
@@ -1464,6 +1737,75 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
             };
             bool ok = !anytie;
             const unsigned saved_rng = rng.s;
+            int ntk = 0; // tied keys of the row
+            if (anytie && wp.tied_fast) {
+                // ---- the tied keys in order, the engine through their runs --------
+#ifdef BXH_WPROF
+                unsigned long long wprof_t = (unsigned long long)clock64();
+#endif
+                ntk = __hip_atomic_load(&tdl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int tflags = __hip_atomic_load(&tdl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = tflags == 0 && ntk >= 1 && ntk <= tk_cap;
+                if (ok) {
+                    // in key order: a bitonic network over the keys and their counts (the keys are distinct)
+                    const int n2t = next_pow2(ntk);
+                    for (int t = tid; t < n2t; t += T) {
+                        unsigned long long key = ~0ull;
+                        int len = 0;
+                        if (t < ntk) {
+                            const int sl = __hip_atomic_load(&tdl[64 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            key = __hip_atomic_load(&htab[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            len = 1 + (int)__hip_atomic_load(&hcount[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        tk_key[t] = key;
+                        tk_len[t] = len;
+                    }
+                    __syncthreads();
+                    for (int kk = 2; kk <= n2t; kk <<= 1)
+                        for (int j = kk >> 1; j > 0; j >>= 1) {
+                            for (int t = tid; t < (n2t >> 1); t += T) {
+                                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                                const int l = i | j;
+                                const unsigned long long ka = tk_key[i], kb = tk_key[l];
+                                if ((ka > kb) == ((i & kk) == 0)) {
+                                    const int la = tk_len[i], lb = tk_len[l];
+                                    tk_key[i] = kb;
+                                    tk_key[l] = ka;
+                                    tk_len[i] = lb;
+                                    tk_len[l] = la;
+                                }
+                            }
+                            __syncthreads();
+                        }
+                    int kinds = 0;
+                    for (int t = tid; t < ntk; t += T) {
+                        const int len = tk_len[t];
+                        kinds |= (len > 512 ? 1 : 0) | (len > 46340 ? 2 : 0);
+                    }
+                    kinds = wide_or_bits(kinds, misc_s + MS_WAVES + 36);
+                    unsigned st_end = rng.s;
+                    ok = !(kinds & 2);
+                    if (ok)
+                        ok = wide_runs_dry(tk_len, tk_base, tk_state, ntk, (kinds & 1) != 0, rng.s, pb.lcg_pow,
+                                           tk_cand, misc_s, &st_end);
+                    if (ok)
+                        rng.s = st_end; // behind the shuffles; select_variables draws next
+                }
+                BXH_WSTAMP(13); // the tied keys in order, the engine through their runs
+            }
+            // elements of the run of `key` (1: not a tied key)
+            auto run_of = [&](unsigned long long key, int& q) -> int {
+                int lo = 0, hi = ntk;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (tk_key[mid] < key)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                q = lo;
+                return (lo < ntk && tk_key[lo] == key) ? tk_len[lo] : 1;
+            };
             int sel = 0;
             unsigned long long k_sel = 0ull, k_sel1 = 0ull;
             if (ok) {
@@ -1485,7 +1827,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                         bool stopped = false;
                         if (cur < nN)
                             cur = nN; // N entries never stop the scan
-                        if (cur <= bkmax && cur < nN + nZ) { // the zero entry
+                        while (!stopped && cur <= bkmax && cur < nN + nZ) { // the zero entries
                             if (rng.coin())
                                 stopped = true;
                             else
@@ -1507,18 +1849,19 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                             sel = cur - 1;
                     }
                 }
+                int qdummy;
                 auto key_at = [&](int rank, bool& good) -> unsigned long long {
                     if (rank == 0)
                         return g1;
                     if (rank == 1)
-                        return second_smallest();
+                        return (anytie && run_of(g1, qdummy) >= 2) ? g1 : second_smallest();
                     if (rank == r - 1)
                         return gx;
                     if (nN > 0 && rank == nN - 1)
                         return gxN;
-                    if (rank == nN)
-                        return nZ ? K0 : gnS;
-                    if (nZ && rank == nN + nZ)
+                    if (rank >= nN && rank < nN + nZ)
+                        return K0;
+                    if (rank == nN + nZ)
                         return gnS;
                     good = false;
                     return 0ull;
@@ -1530,10 +1873,31 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 } else {
                     k_sel = key_at(sel, ok);
                     k_sel1 = key_at(sel + 1, ok);
+                    if (ok && anytie && k_sel1 == k_sel) {
+                        // the selected position splits a run: where the run starts, how long it is
+                        int q = 0;
+                        const int len = run_of(k_sel, q);
+                        int first = -1;
+                        if (k_sel == g1)
+                            first = 0;
+                        else if (k_sel == K0)
+                            first = nN;
+                        else if (k_sel == gnS)
+                            first = nN + nZ;
+                        if (len < 2 || first < 0 || len > WIDE_TRUN || sel < first || sel + 1 >= first + len)
+                            ok = false;
+                        else {
+                            f_split = true;
+                            f_split_q = q;
+                            f_split_off = sel - first;
+                            f_split_len = len;
+                        }
+                    }
                 }
             }
             if (!ok) {
-                rng.s = saved_rng; // the sort path redoes the scan
+                rng.s = saved_rng; // the sort path redoes the shuffles and the scan
+                f_split = false;
             } else {
                 const Float one = 1, two = 2;
                 const Float middle = (two + one) / two;
@@ -1562,6 +1926,69 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
             }
         }
 
+#ifdef BXH_WPROF
+        if (tid == 0 && grp == 0 && st.prof && row_tied) { // tied rows: fast, fast with a split run, sorted
+            unsigned long long* pr = st.prof + (size_t)inst * 32;
+            pr[24] += fast ? 1ull : 0ull;
+            pr[25] += (fast && f_split) ? 1ull : 0ull;
+            pr[26] += fast ? 0ull : 1ull;
+        }
+#endif
+        if (fast && f_split) {
+            // ---- the run the selected position splits: std::shuffle of its members --
+            // (in the order calculator_sort leaves them in: ascending position in the row)
+            int mine = 0;
+            for (int l = tid; l < cnt; l += T)
+                mine += order_key<Float>(val_s[l], maximize) == f_thr ? 1 : 0;
+            mine = wave_sum(mine);
+            if (tid == 0)
+                misc_s[MS_WAVES + 33] = 0;
+            __syncthreads();
+            if (lane == 0 && mine)
+                atomicAdd(&misc_s[MS_WAVES + 33], mine);
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(&tdl[8 + grp], misc_s[MS_WAVES + 33], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (!wide_sync(cnt_sl, (unsigned)G * (nslow + 1u), err_word, misc_s + WM_DEAD)) {
+                dead = true;
+                break;
+            }
+            ++nslow;
+            int before = 0; // members in the workgroups in front of this one
+            for (int g = 0; g < grp; ++g)
+                before += __hip_atomic_load(&tdl[8 + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ordinals of the own members, ascending in l: a block of T positions at a time
+            for (int l0 = 0; l0 < cnt; l0 += T) {
+                const int l = l0 + tid;
+                const bool mem = l < cnt && order_key<Float>(val_s[l], maximize) == f_thr;
+                const unsigned long long mask = __ballot(mem);
+                if (lane == 0)
+                    misc_s[MS_WAVES + wave] = __popcll(mask);
+                __syncthreads();
+                int off = before;
+                for (int w = 0; w < wave; ++w)
+                    off += misc_s[MS_WAVES + w];
+                int blk = 0;
+                for (int w = 0; w < T / 64; ++w)
+                    blk += misc_s[MS_WAVES + w];
+                if (l < cnt)
+                    tk_ord[l] = mem ? off + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+                before += blk;
+                __syncthreads();
+            }
+            // the shuffle itself, on the ordinals: one lane, the engine as it stood in front of the run
+            for (int i = tid; i < f_split_len; i += T)
+                tk_list[i] = i;
+            __syncthreads();
+            if (tid == 0)
+                lane_run_shuffle(tk_list, (unsigned)f_split_len, tk_state[f_split_q]);
+            __syncthreads();
+            for (int p_ = tid; p_ < f_split_len; p_ += T)
+                tk_inv[tk_list[p_]] = p_;
+            __syncthreads();
+        }
+
         if (fast) {
             // ---- affect without the sorted order ------------------------------
             __syncthreads(); // every thread has read pi_k
@@ -1580,6 +2007,8 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 const int j = pb.row_col[e];
                 const int pe = pb.row_pos[e];
                 bool up = f_mode == 1 || (f_mode == 2 && key <= f_thr);
+                if (f_split && key == f_thr) // in front of the selected position, or at it?
+                    up = tk_inv[tk_ord[l]] <= f_split_off;
                 if (PM1 && pb.fac_csr[e] < 0)
                     up = !up;
                 const Float p = pown_s[l]; // P[pe] * theta
@@ -1644,7 +2073,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                         int b0 = 0;
                         for (int i = 1; i <= r; ++i) {
                             if (i == r || key_s[i] != key_s[b0]) {
-                                rng.shuffle(id_s + b0, (unsigned)(i - b0));
+                                rng.shuffle_inl(id_s + b0, (unsigned)(i - b0));
                                 b0 = i;
                             }
                         }
@@ -1788,8 +2217,14 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 if (coop) {
                     if (!wide_sort_coop<Float>(vbuf, r, n2, maximize, grp, G, bkey0 + (size_t)G * wp.n2big,
                                                bid0 + (size_t)G * wp.n2big, bkey0 + (size_t)(G + 1) * wp.n2big,
-                                               bid0 + (size_t)(G + 1) * wp.n2big, bkey, bid, lk, li, Cc, cnt_sl,
-                                               nslow, err_word, misc_s + WM_DEAD)) {
+                                               bid0 + (size_t)(G + 1) * wp.n2big, bid, lk, li, Cc, cnt_sl,
+                                               nslow, err_word, misc_s + WM_DEAD
+#ifdef BXH_WPROF
+                                               ,
+                                               (tid == 0 && grp == 0 && st.prof) ? st.prof + (size_t)inst * 32
+                                                                                  : nullptr
+#endif
+                                               )) {
                         dead = true;
                         break;
                     }
@@ -1815,135 +2250,164 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                         bitonic_sort(bkey, bid, n2);
                 }
                 BXH_WSTAMP(0); // the sort
-                for (int i = tid; i + 1 < r; i += T)
-                    if (bkey[i] == bkey[i + 1])
-                        misc_s[MS_TIE] = 1;
-                __syncthreads();
-                BXH_WSTAMP(1); // tie detection
+                // the sorted keys: this workgroup's own copy, or -- after the shared sort -- the one
+                // copy of the instance, read through L2 (its lines may sit in this CU's L1 from an
+                // earlier row)
+                const bool shared_keys = coop;
+                if (coop)
+                    bkey = bkey0 + (size_t)(G + 1) * (size_t)wp.n2big;
+                auto bk = [&](int i) -> unsigned long long {
+                    return shared_keys
+                             ? __hip_atomic_load(&bkey[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : bkey[i];
+                };
                 // ---- the tied runs.  Draw number g of the row's engine is a jump of the
                 // linear congruential engine, and a run of L elements takes L / 2 draws
                 // unless one is rejected: so every run's first draw is known from the run
-                // lengths, the runs can be shuffled side by side (one wave each: runs of
+                // lengths, the runs can be shuffled side by side (one lane each: runs of
                 // up to 512; all threads: up to 2048), and one pass over all draws tells
                 // whether -- and in which run first -- a rejection shifts the stream; from
                 // that run on thread 0 shuffles serially, as for rows with too many runs.
                 int serial_head = 0;     // first position left to thread 0's serial shuffle
                 unsigned serial_state = rng.s;
                 bool runs_listed = false;
-                if (misc_s[MS_TIE]) {
-                    int* rl_head = (int*)uni;
-                    const int RCAP = lp.union_bytes / 12;
-                    int* rl_len = rl_head + RCAP;
-                    int* rl_base = rl_len + RCAP;
-                    // ordered lists of the runs' first and last positions.  Every wave takes one
-                    // contiguous stretch of the row (whole 64-position steps: coalesced reads), counts
-                    // its heads and tails, and after ONE barrier writes them behind those of the waves
-                    // in front of it: two barriers per row (rounds 2 - 4: two per 512 positions and
-                    // pass, 160 for a row of 20 000 elements -- half of what a tied row cost on top).
-                    int nh = 0, nt = 0;
-                    {
-                        const int NWv = T / 64;
-                        const int seg = (((r + NWv - 1) / NWv) + 63) & ~63;
-                        const int s0 = wave * seg, s1 = min(r, s0 + seg);
-                        auto flags = [&](int i, bool& fh, bool& ft) {
-                            fh = ft = false;
-                            if (i < s1) {
-                                const unsigned long long ki = bkey[i];
-                                const bool eq_next = i + 1 < r && bkey[i + 1] == ki;
-                                const bool eq_prev = i > 0 && bkey[i - 1] == ki;
-                                fh = eq_next && !eq_prev;
-                                ft = eq_prev && !eq_next;
-                            }
-                        };
-                        int ch = 0, ct = 0;
-                        for (int c0 = s0; c0 < s1; c0 += 64) {
-                            bool fh, ft;
-                            flags(c0 + lane, fh, ft);
-                            ch += __popcll(__ballot(fh));
-                            ct += __popcll(__ballot(ft));
+                int* rl_head = (int*)uni;
+                const int RCAP = lp.union_bytes / 12;
+                int* rl_len = rl_head + RCAP;
+                int* rl_base = rl_len + RCAP;
+                // ordered lists of the runs' first and last positions.  Every wave takes one
+                // contiguous stretch of the row (whole 64-position steps: coalesced reads), counts
+                // its heads and tails, and after ONE barrier writes them behind those of the waves
+                // in front of it: two barriers per row (rounds 2 - 4: two per 512 positions and
+                // pass, 160 for a row of 20 000 elements -- half of what a tied row cost on top).
+                // The keys of four steps are in flight together, a position's neighbours come from
+                // the lanes next to it, and "is there a tie at all" is the count of the heads.
+                int nh = 0, nt = 0;
+                {
+                    const int NWv = T / 64;
+                    const int seg = (((r + NWv - 1) / NWv) + 63) & ~63;
+                    const int s0 = min(r, wave * seg), s1 = min(r, s0 + seg);
+                    // heads / tails among the positions c0 ... c0 + 255 below s1, as ballots
+                    auto run_marks = [&](int c0, unsigned long long (&mh)[4], unsigned long long (&mt)[4]) {
+                        unsigned long long kc[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = c0 + 64 * u + lane;
+                            kc[u] = i < r ? bk(i) : 0ull;
                         }
-                        if (lane == 0) {
-                            misc_s[MS_WAVES + wave] = ch;
-                            misc_s[MS_WAVES + 16 + wave] = ct;
+                        const unsigned long long kfront = c0 > 0 ? bk(c0 - 1) : 0ull;
+                        const unsigned long long kback = c0 + 256 < r ? bk(c0 + 256) : 0ull;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = c0 + 64 * u + lane;
+                            unsigned long long kn = __shfl(kc[u], (lane + 1) & 63);
+                            unsigned long long kp = __shfl(kc[u], (lane + 63) & 63);
+                            const unsigned long long kn_edge = u < 3 ? __shfl(kc[u < 3 ? u + 1 : u], 0) : kback;
+                            const unsigned long long kp_edge = u > 0 ? __shfl(kc[u > 0 ? u - 1 : u], 63) : kfront;
+                            if (lane == 63)
+                                kn = kn_edge;
+                            if (lane == 0)
+                                kp = kp_edge;
+                            const bool in = i < s1;
+                            const bool eq_next = in && i + 1 < r && kn == kc[u];
+                            const bool eq_prev = in && i > 0 && kp == kc[u];
+                            mh[u] = __ballot(eq_next && !eq_prev);
+                            mt[u] = __ballot(eq_prev && !eq_next);
                         }
-                        __syncthreads();
-                        int offh = 0, offt = 0;
-                        for (int w = 0; w < NWv; ++w) {
-                            const int cw = misc_s[MS_WAVES + w], tw = misc_s[MS_WAVES + 16 + w];
-                            if (w < wave) {
-                                offh += cw;
-                                offt += tw;
-                            }
-                            nh += cw;
-                            nt += tw;
+                    };
+                    int ch = 0, ct = 0;
+                    for (int c0 = s0; c0 < s1; c0 += 256) {
+                        unsigned long long mh[4], mt[4];
+                        run_marks(c0, mh, mt);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            ch += __popcll(mh[u]);
+                            ct += __popcll(mt[u]);
                         }
-                        for (int c0 = s0; c0 < s1; c0 += 64) {
-                            const int i = c0 + lane;
-                            bool fh, ft;
-                            flags(i, fh, ft);
-                            const unsigned long long mh = __ballot(fh), mt = __ballot(ft);
-                            const unsigned long long below = (1ull << lane) - 1ull;
-                            const int ph = offh + __popcll(mh & below), pt = offt + __popcll(mt & below);
-                            if (fh && ph < RCAP)
-                                rl_head[ph] = i;
-                            if (ft && pt < RCAP)
-                                rl_len[pt] = i; // (the last position, for now)
-                            offh += __popcll(mh);
-                            offt += __popcll(mt);
-                        }
-                        __syncthreads();
                     }
+                    if (lane == 0) {
+                        misc_s[MS_WAVES + wave] = ch;
+                        misc_s[MS_WAVES + 16 + wave] = ct;
+                    }
+                    __syncthreads();
+                    int offh = 0, offt = 0;
+                    for (int w = 0; w < NWv; ++w) {
+                        const int cw = misc_s[MS_WAVES + w], tw = misc_s[MS_WAVES + 16 + w];
+                        if (w < wave) {
+                            offh += cw;
+                            offt += tw;
+                        }
+                        nh += cw;
+                        nt += tw;
+                    }
+                    BXH_WSTAMP(1); // tie detection = the runs counted
+                    if (nh > 0 && nh <= RCAP) {
+                        for (int c0 = s0; c0 < s1; c0 += 256) {
+                            unsigned long long mh[4], mt[4];
+                            run_marks(c0, mh, mt);
+                            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int i = c0 + 64 * u + lane;
+                                const int ph = offh + __popcll(mh[u] & below), pt = offt + __popcll(mt[u] & below);
+                                if ((mh[u] >> lane) & 1ull)
+                                    rl_head[ph] = i;
+                                if ((mt[u] >> lane) & 1ull)
+                                    rl_len[pt] = i; // (the last position, for now)
+                                offh += __popcll(mh[u]);
+                                offt += __popcll(mt[u]);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                const bool tied = nh > 0;
+                if (tied) {
                     BXH_WSTAMP(2); // the runs listed
                     const int nruns = nh;
                     (void)nt;
+                    int run_kinds = 0; // bit 0: a run of more than 512 elements; bit 1: of more than 46 340
                     if (nruns <= RCAP) {
+                        int mine = 0;
+                        for (int q = tid; q < nruns; q += T) {
+                            const int len = rl_len[q] - rl_head[q] + 1;
+                            rl_len[q] = len;
+                            mine |= (len > 512 ? 1 : 0) | (len > 46340 ? 2 : 0);
+                        }
+                        run_kinds = wide_or_bits(mine, misc_s + MS_WAVES + 36);
+                    }
+                    // (beyond 46 340 elements std::shuffle draws once per element, not once per pair:
+                    // the draw numbers below do not hold for such a row -- thread 0 takes it whole)
+                    if (nruns <= RCAP && !(run_kinds & 2)) {
                         runs_listed = true;
-                        for (int q = tid; q < nruns; q += T)
-                            rl_len[q] = rl_len[q] - rl_head[q] + 1;
-                        __syncthreads();
+                        const bool has_long = (run_kinds & 1) != 0;
+#ifdef BXH_WPROF
+                        if (tid == 0 && grp == 0 && st.prof) { // the row's runs: how many, how long
+                            unsigned long long tot = 0, mx = 0;
+                            for (int q = 0; q < nruns; ++q) {
+                                tot += (unsigned long long)rl_len[q];
+                                mx = max(mx, (unsigned long long)rl_len[q]);
+                            }
+                            unsigned long long* pr = st.prof + (size_t)inst * 32;
+                            pr[16] += (unsigned long long)nruns;
+                            pr[17] += tot;
+                            pr[18] = max(pr[18], mx);
+                            pr[19] += 1ull;
+                            pr[20] += (unsigned long long)r;
+                            pr[21] = max(pr[21], (unsigned long long)(nruns + (r - (int)tot)));
+                            pr[22] += (unsigned long long)(nruns + (r - (int)tot));
+                        }
+#endif
                         int qb = 0;               // runs in front of qb are done
                         unsigned st_row = rng.s;  // the engine in front of run qb
                         while (qb < nruns) {
-                            if (tid == 0) {
-                                int acc = 0;
-                                for (int q = qb; q < nruns; ++q) {
-                                    rl_base[q] = acc;
-                                    acc += rl_len[q] >> 1;
-                                }
-                                misc_s[WM_TAKE] = nruns;   // first run with a rejected draw
-                                misc_s[WM_FLAG] = acc;     // draws of the runs from qb on
-                            }
-                            __syncthreads();
-                            const int total_draws = misc_s[WM_FLAG];
-                            const bool table_ok = total_draws + 1 < WIDE_LCG_POW;
-                            // pass over all draws: is any rejected?
-                            if (table_ok) {
-                                for (int q = qb + wave; q < nruns; q += T / 64) {
-                                    const int L = rl_len[q], bq = rl_base[q];
-                                    const bool even = (L & 1) == 0;
-                                    bool rej = false;
-                                    for (int d = lane; d < (L >> 1); d += 64) {
-                                        unsigned urange;
-                                        if (even && d == 0)
-                                            urange = 1u;
-                                        else {
-                                            const unsigned i0 = even ? 2u * (unsigned)d : 2u * (unsigned)d + 1u;
-                                            urange = (i0 + 1u) * (i0 + 2u) - 1u;
-                                        }
-                                        const unsigned uerange = urange + 1u;
-                                        const unsigned scaling = 2147483645u / uerange;
-                                        const unsigned past = uerange * scaling;
-                                        const unsigned raw = lcg_jump(pb.lcg_pow, st_row, bq + d + 1) - 1u;
-                                        rej |= raw >= past;
-                                    }
-                                    if (__ballot(rej) != 0ull && lane == 0)
-                                        atomicMin(&misc_s[WM_TAKE], q);
-                                }
-                            } else if (tid == 0)
-                                misc_s[WM_TAKE] = qb;
-                            __syncthreads();
+                            // which run from qb on is the first with a rejected draw?
+                            int total_draws = 0;
+                            int first_rej = wide_first_rejection(rl_len, rl_base, qb, nruns, has_long, st_row,
+                                                                 pb.lcg_pow, (int*)ring_s, misc_s, &total_draws);
+                            if (first_rej < 0) // (more draws than the table of the engine's powers holds)
+                                first_rej = qb;
                             BXH_WSTAMP(3); // every draw checked for a rejection
-                            const int first_rej = misc_s[WM_TAKE];
                             // the runs in front of it, side by side: one LANE per run of up to 512
                             // elements (round 5).  No draw of these runs is rejected (checked above),
                             // so run q starts at draw rl_base[q] of the row's engine, and its shuffle is
@@ -1969,7 +2433,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                                 const int cap_run = min(2048, ring_bytes / 12);
                                 int* jt_l = ids_l + cap_run;
                                 int* out_l = jt_l + cap_run;
-                                for (int q = qb; q < first_rej; ++q) {
+                                for (int q = qb; has_long && q < first_rej; ++q) {
                                     const int L = rl_len[q];
                                     if (L <= 512)
                                         continue;
@@ -1988,7 +2452,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                                         if (tid == 0) {
                                             MinStd e;
                                             e.s = stq;
-                                            e.shuffle(bid + head, (unsigned)L);
+                                            e.shuffle_inl(bid + head, (unsigned)L);
                                         }
                                         __syncthreads();
                                     }
@@ -2011,9 +2475,9 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                                     MinStd e;
                                     e.s = stq;
                                     if (in_lds)
-                                        e.shuffle(ids_l, (unsigned)L);
+                                        e.shuffle_inl(ids_l, (unsigned)L);
                                     else
-                                        e.shuffle(bid + head, (unsigned)L);
+                                        e.shuffle_inl(bid + head, (unsigned)L);
                                     misc_s[MS_RNG] = (int)e.s;
                                 }
                                 __syncthreads();
@@ -2041,13 +2505,16 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 if (tid == 0) {
                     if (grp == 0)
                         alg_bytes += pb.row_bytes[k];
-                    if (misc_s[MS_TIE]) { // what is left of the tied runs (all of them when the
+                    if (tied) { // what is left of the tied runs (all of them when the
                         rng.s = runs_listed ? serial_state : rng.s; // runs were not listed), serially
                         int b0 = runs_listed ? serial_head : 0;
+                        unsigned long long kb0 = b0 < r ? bk(b0) : 0ull;
                         for (int i = b0 + 1; i <= r; ++i) {
-                            if (i == r || bkey[i] != bkey[b0]) {
-                                rng.shuffle(bid + b0, (unsigned)(i - b0));
+                            const unsigned long long ki = i < r ? bk(i) : 0ull;
+                            if (i == r || ki != kb0) {
+                                rng.shuffle_inl(bid + b0, (unsigned)(i - b0));
                                 b0 = i;
+                                kb0 = ki;
                             }
                         }
                     }
@@ -2080,7 +2547,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                             int lo = 0, hi = r;
                             while (lo < hi) {
                                 const int mid = (lo + hi) >> 1;
-                                if (bkey[mid] < K0)
+                                if (bk(mid) < K0)
                                     lo = mid + 1;
                                 else
                                     hi = mid;
@@ -2089,7 +2556,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                             hi = r;
                             while (lo < hi) {
                                 const int mid = (lo + hi) >> 1;
-                                if (bkey[mid] <= K0)
+                                if (bk(mid) <= K0)
                                     lo = mid + 1;
                                 else
                                     hi = mid;
@@ -2167,11 +2634,18 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 }
             }
         }
-        // the row's keys leave the tie table
+        // the row's keys leave the tie table (with their counts and the list of the tied ones)
         for (int l = tid; l < cnt; l += T) {
             const int s = hslot_s[l];
-            if (s >= 0)
+            if (s >= 0) {
                 __hip_atomic_exchange(&htab[s], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (row_tied && wp.tied_fast)
+                    __hip_atomic_store(&hcount[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (row_tied && wp.tied_fast && grp == 0 && tid == 0) {
+            __hip_atomic_store(&tdl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&tdl[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- second meeting of the row: affect's stores have landed --------
         if (!wide_sync(cnt_s2, (unsigned)G * (unsigned)(it + 1), err_word, misc_s + WM_DEAD)) {

@@ -22,10 +22,12 @@ pytestmark = pytest.mark.gpu
 WIDE_CASES = [c for c in CASES if c[4] in (0, 1, 2)]
 
 
-@pytest.mark.parametrize("groups", ["w1", "w2", "w3"])
+@pytest.mark.parametrize("groups", ["w1", "w2", "w3", "w2-sorted"])
 @pytest.mark.parametrize("case", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
 def test_wide_kernel_small_cases(oracle, bxh, case, groups, monkeypatch):
     monkeypatch.delenv("BXH_FORCE_V1", raising=False)
+    _tied(monkeypatch, "sorted" if groups.endswith("-sorted") else "fast")
+    groups = groups.split("-")[0]
     monkeypatch.setenv("BXH_GROUPS", groups)
     _, maker, float_type, maximize, order, x0p = case
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p, expect_form=100 + int(groups[1:]))
@@ -42,16 +44,31 @@ def test_wide_kernel_edge_shapes(oracle, bxh, case, groups, monkeypatch):
     run_case(oracle, bxh, maker(), float_type, maximize, order, x0p, sweeps=8, push_at=(3, 6))
 
 
+TIED = pytest.mark.parametrize("tied", ["fast", "sorted"])
+
+
+def _tied(monkeypatch, tied):
+    """"sorted": every row with equal reduced costs goes through the sort path (BXH_WIDE_TIEDFAST=0);
+    "fast": the default -- the tied keys and their counts out of the tie table, no sorted order, where
+    the selection allows it."""
+    if tied == "sorted":
+        monkeypatch.setenv("BXH_WIDE_TIEDFAST", "0")
+    else:
+        monkeypatch.delenv("BXH_WIDE_TIEDFAST", raising=False)
+
+
+@TIED
 @pytest.mark.parametrize("groups,cols,own", [("w4", 30000, False), ("w3", 30000, False), ("w2", 70000, False),
                                              ("w4", 30000, True)],
                          ids=["w4-chunk-each", "w3-one-idle", "w2-two-chunks-each", "w4-own-sort"])
-def test_wide_kernel_long_tied_rows(oracle, bxh, groups, cols, own, monkeypatch):
+def test_wide_kernel_long_tied_rows(oracle, bxh, groups, cols, own, tied, monkeypatch):
     """Rows of ~3000 (7000) elements with integer costs: every row of the first
     sweep holds runs of equal reduced costs (the long-row sort and its shuffles).
     The workgroups of an instance sort the row together -- a chunk of 1024 pairs
     each (4 workgroups), 2 chunks of 2048 for 3 workgroups (one has none), 4 chunks
     of 2048 for 2 workgroups -- or (BXH_WIDE_OWN_SORT) every one the whole row."""
     monkeypatch.setenv("BXH_GROUPS", groups)
+    _tied(monkeypatch, tied)
     if own:
         monkeypatch.setenv("BXH_WIDE_OWN_SORT", "1")
     inst = synth.make_scp(40, cols, 0.1, "int", 95)
@@ -59,8 +76,9 @@ def test_wide_kernel_long_tied_rows(oracle, bxh, groups, cols, own, monkeypatch)
              expect_form=100 + int(groups[1:]))
 
 
+@TIED
 @pytest.mark.parametrize("ncost", [2, 6, 40], ids=["runs-of-1500", "runs-of-500", "runs-of-75"])
-def test_wide_kernel_long_rows_tied_runs_side_by_side(oracle, bxh, ncost, monkeypatch):
+def test_wide_kernel_long_rows_tied_runs_side_by_side(oracle, bxh, ncost, tied, monkeypatch):
     """40 rows of 3000 elements whose integer costs take `ncost` values, among
     4200 rows (so that the pi window -- the LDS scratch of the long-row path -- is
     64 KB as at the XL shape): the tied runs of a row are shuffled side by side
@@ -68,6 +86,7 @@ def test_wide_kernel_long_rows_tied_runs_side_by_side(oracle, bxh, ncost, monkey
     one thread (longer), and with runs this long some draw is rejected in almost
     every row (the scheme restarts behind that run)."""
     monkeypatch.setenv("BXH_GROUPS", "w4")
+    _tied(monkeypatch, tied)
     rs = np.random.RandomState(400 + ncost)
     n, nlong, m = 12000, 40, 4200
     rows = [np.sort(rs.choice(n, size=3000, replace=False)) for _ in range(nlong)]
@@ -75,6 +94,41 @@ def test_wide_kernel_long_rows_tied_runs_side_by_side(oracle, bxh, ncost, monkey
     costs = rs.randint(1, ncost + 1, n).astype(float)
     inst = _custom(rows, n, [1] * m, [2 ** 30] * m, costs, kind=1)
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=3, push_at=(2,), expect_form=104)
+
+
+@pytest.mark.parametrize("ncost", [2500, 14000], ids=["1700-tied-keys", "around-1000-tied-keys"])
+def test_wide_kernel_many_tied_keys(oracle, bxh, ncost, monkeypatch):
+    """Rows of 6000 elements over `ncost` integer cost values: ~1700 tied keys a row (more than the 1024 the
+    path without a sort takes: the row is sorted) and ~980 (rows on either side of that limit)."""
+    monkeypatch.setenv("BXH_GROUPS", "w4")
+    rs = np.random.RandomState(77 + ncost)
+    n, nlong, m = 16000, 30, 4200
+    rows = [np.sort(rs.choice(n, size=6000, replace=False)) for _ in range(nlong)]
+    rows += [np.array([rs.randint(n)]) for _ in range(m - nlong)]
+    costs = rs.randint(1, ncost + 1, n).astype(float)
+    inst = _custom(rows, n, [1] * m, [2 ** 30] * m, costs, kind=1)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=3, push_at=(2,), expect_form=104)
+
+
+@TIED
+def test_wide_kernel_rejected_draw_among_runs_of_a_lane_each(oracle, bxh, tied, monkeypatch):
+    """60 rows of 20 000 elements (columns of their own) over 48 cost values: ~48 runs of ~420 equal
+    reduced costs a row, none beyond 512 -- every run is shuffled by a lane of its own, and whether a draw
+    of the row is rejected (which shifts the engine for every run behind it) is decided from one comparison
+    per draw against the widest range, the exact test only for the draws that pass it.  A run of 420
+    elements sees a rejected draw with probability ~0.3 %, a row with ~13 %: over 60 rows and three sweeps
+    one is certain for every practical purpose (and checked once by breaking the exact test on purpose:
+    the case fails then)."""
+    monkeypatch.setenv("BXH_GROUPS", "w16")
+    _tied(monkeypatch, tied)
+    rs = np.random.RandomState(4242)
+    nlong, rlen, m = 60, 20000, 4200
+    n = nlong * rlen
+    rows = [np.arange(i * rlen, (i + 1) * rlen) for i in range(nlong)]
+    rows += [np.array([rs.randint(n)]) for _ in range(m - nlong)]
+    costs = rs.randint(1, 49, n).astype(float)
+    inst = _custom(rows, n, [1] * m, [2 ** 30] * m, costs, kind=1)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=3, push_at=(2,), expect_form=116)
 
 
 def test_wide_kernel_bench_geometry(oracle, bxh, monkeypatch):

@@ -29,6 +29,19 @@ names = ["sort", "tie detection", "runs listed", "rejection pre-pass", "short ru
          "long runs / behind a rejection", "thread 0: rest, selection, pi, d"]
 rows = steps * args.xl_sweep_rows
 print(f"kernel {ms / n:.2f} ms per launch, {rows} row updates per instance in {steps} launches")
-tot = t[:, :7].astype(np.float64).mean(axis=0)
+names += [None, "  sort: own chunk sorted, published", "  sort: first meeting", "  sort: final positions",
+          "  sort: second meeting", "  sort: the copy of the sorted row",
+          "tied, no sort: keys ordered, engine"]
+tot = t[:, :len(names)].astype(np.float64).mean(axis=0)
 for nm, v in zip(names, tot):
-    print(f"  {nm:36s} {v / rows / 2400.0:8.2f} us per row update (2.4 GHz ticks)")
+    if nm:
+        print(f"  {nm:36s} {v / rows / 2400.0:8.2f} us per row update (2.4 GHz ticks)")
+
+st = t[:, 16:23].astype(np.float64)
+rows_t = st[:, 3].mean()
+if rows_t > 0:
+    print(f"tied long rows per instance: {rows_t:.0f} of {rows}; per tied row: {st[:, 0].mean() / rows_t:.1f} runs, "
+          f"{st[:, 1].mean() / rows_t:.0f} of {st[:, 4].mean() / rows_t:.0f} elements in runs, longest run {st[:, 2].max():.0f}, "
+          f"distinct keys {st[:, 6].mean() / rows_t:.0f} on average, {st[:, 5].max():.0f} at most")
+tf = t[:, 24:27].astype(np.float64).mean(axis=0)
+print(f"tied rows per instance: {tf[0]:.0f} without a sort ({tf[1]:.0f} of them with a split run), {tf[2]:.0f} sorted")
