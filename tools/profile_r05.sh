@@ -7,6 +7,9 @@
 #                                256 restarts, so that "issue-bound, not memory-bound" has counters behind it
 #   tools/profile_r05.sh multi   two ranks on the one GPU (gloo): the exchange inside the timed region
 #   tools/profile_r05.sh host    tools/e2e_workers.py: host microseconds per round of optimize() by workers
+#   tools/profile_r05.sh c4      configs[3] (100 000 x 1 000 000) with integer and with real costs: kernel stats,
+#                                FETCH_SIZE / WRITE_SIZE passes, bench lines (and the integer line with every tied
+#                                row sorted, BXH_WIDE_TIEDFAST=0)
 # Each rocprofv3 command profiles `python3 bench.py` directly (no wrapper between `--` and the program).
 set -o pipefail
 WHAT=${1:-all}
@@ -39,5 +42,16 @@ if [ "$WHAT" = host ] || [ "$WHAT" = all ]; then
   run python3 tools/e2e_workers.py c1 200 > $O/e2e_workers_c1.jsonl 2>&1 || exit 1
   run python3 tools/e2e_workers.py c5 100 64 256 1024 > $O/e2e_workers_c5.jsonl 2>&1 || exit 1
   run python3 tools/e2e_workers.py c2 50 64 256 1024 > $O/e2e_workers_c2.jsonl 2>&1 || exit 1
+fi
+if [ "$WHAT" = c4 ]; then
+  for kind in int real; do
+    C4="python3 bench.py --config c4 --cost-kind $kind --warmup 1 --cpu-seconds 0"
+    run rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_${kind}_stats -- $C4 --steps 4 > $O/c4_${kind}_stats.log 2>&1 || exit 1
+    run rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c4_${kind}_fetch -- $C4 --steps 3 > $O/c4_${kind}_fetch.log 2>&1 || exit 1
+    run rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c4_${kind}_write -- $C4 --steps 3 > $O/c4_${kind}_write.log 2>&1 || exit 1
+  done
+  run python3 bench.py --config c4 --cost-kind int --steps 4 --warmup 1 > $O/bench_line_c4_int.json 2> $O/bench_line_c4_int.err || exit 1
+  run python3 bench.py --config c4 --cost-kind real --steps 4 --warmup 1 --cpu-seconds 0 > $O/bench_line_c4_real.json 2> $O/bench_line_c4_real.err || exit 1
+  BXH_WIDE_TIEDFAST=0 run python3 bench.py --config c4 --cost-kind int --steps 4 --warmup 1 --cpu-seconds 0 > $O/bench_line_c4_int_sorted.json 2> $O/bench_line_c4_int_sorted.err || exit 1
 fi
 echo done
