@@ -1183,6 +1183,11 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
     constexpr int T = WIDE_T;
     const int lane = tid & 63, wave = tid >> 6;
     const WideLds lp = wide_lds(G, wp.chmax, (int)sizeof(Float), wp.ring);
+#ifdef BXH_LDS_POISON // (diagnostic, tools/debug/hunt.sh: whatever reads LDS before writing it gets this pattern)
+    for (int i = tid; i < lp.total / 4; i += T)
+        ((unsigned*)smem)[i] = BXH_LDS_POISON;
+    __syncthreads();
+#endif
     Float* ring_s = (Float*)(smem + lp.off_ring);
     int* misc_s = (int*)(smem + lp.off_misc);
     Float* d_s = (Float*)(misc_s + MS_D);
