@@ -127,6 +127,7 @@ set_lds_limits(int device)
     BXH_SET_LDS(bxh::sweep_kernel_sw<double, true>);
     BXH_SET_LDS(bxh::sweep_kernel_z<float, true>);
     BXH_SET_LDS(bxh::sweep_kernel_z<double, true>);
+    BXH_SET_LDS(bxh::wide_flags_band_kernel);
     BXH_SET_LDS(bxh::order_post_kernel<float>);
     BXH_SET_LDS(bxh::order_post_kernel<double>);
     BXH_SET_LDS(bxh::order_init_kernel<float>);
@@ -368,7 +369,7 @@ struct bxh_handle_s
     DevBuf<unsigned char> piw;
     DevBuf<unsigned long long> whash, wrec, vbuf, bkey;
     DevBuf<unsigned> wcnt, wcount;
-    DevBuf<int> wdl;
+    DevBuf<int> wdl, vsum; // vsum: [m][16] sums of the band scan (wide_flags_band_kernel), when it applies
     DevBuf<int> bid, vflag32;
     bxh::WideParams wp{};
 
@@ -551,7 +552,17 @@ launch_wide_scan(bxh_handle h, const unsigned char* dev_active)
                        h->ds, h->xt.p, h->batch);
     HIP_TRY(hipGetLastError());
     const int blocks = std::max(1, std::min(2048, (h->m + 7) / 8));
-    if (h->batch <= 16)
+    if (h->vsum.p) { // x out of LDS, a band of columns per workgroup (bxh_wide.hpp)
+        const int nbands = (h->n + bxh::WIDE_BAND - 1) / bxh::WIDE_BAND;
+        const int nchunks = std::max(1, std::min(device_cus(h->device) / nbands, (h->m + 63) / 64));
+        const size_t lds = (static_cast<size_t>(std::min(h->n, bxh::WIDE_BAND)) * 2 + 15) & ~size_t(15);
+        hipLaunchKernelGGL(bxh::wide_flags_band_kernel, dim3(nbands * nchunks), dim3(1024), lds, h->stream, h->dp,
+                           h->xt.p, h->vsum.p, nbands, nchunks);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(bxh::wide_flags_finish_kernel,
+                           dim3(static_cast<unsigned>((static_cast<size_t>(h->m) * 16 + 255) / 256)), dim3(256), 0,
+                           h->stream, h->dp, h->wp, h->vsum.p, dev_active, h->batch);
+    } else if (h->batch <= 16)
         hipLaunchKernelGGL((bxh::wide_flags_all_kernel<16>), dim3(blocks), dim3(512), 0, h->stream, h->dp,
                            h->wp, h->xt.p, dev_active, h->batch);
     else
@@ -1664,6 +1675,19 @@ bxh_create(const bxh_problem* pb,
         HIP_TRY(h->vflag32.alloc(B * static_cast<size_t>(m)));
         if (batch <= 32 && !std::getenv("BXH_WIDE_OWN_SCAN"))
             HIP_TRY(h->xt.alloc(static_cast<size_t>(n)));
+        {
+            // the band scan: up to 16 instances of a 01 matrix whose rows list their columns in ascending order
+            bool sorted = !pm1 && batch <= 16 && h->xt.p != nullptr;
+            for (int k = 0; sorted && k != m; ++k)
+                for (int e = pb->row_ptr[k] + 1; e < pb->row_ptr[k + 1]; ++e)
+                    if (pb->col[e] <= pb->col[e - 1]) {
+                        sorted = false;
+                        break;
+                    }
+            const char* eb = std::getenv("BXH_WIDE_BAND_SCAN");
+            if (sorted && !(eb && eb[0] == '0'))
+                HIP_TRY(h->vsum.alloc(static_cast<size_t>(m) * 16));
+        }
         HIP_TRY(h->wcount.alloc(B * hs)); // zeros: no key has a duplicate, no tied key is listed
         HIP_TRY(h->wdl.alloc(B * static_cast<size_t>(bxh::WIDE_TDL)));
         HIP_TRY(hipMemsetAsync(h->wcount.p, 0, B * hs * sizeof(unsigned), h->own_stream));
@@ -1922,9 +1946,10 @@ bxh_create_device(const bxh_problem* pb,
     int scal_h[2] = { 0, 0 };
     HIP_TRY(hipMemcpyAsync(scal_h, scal.p, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (scal_h[1])
+    if (scal_h[1] & 1)
         return fail(BXH_ERR_INVALID,
                     "empty row, column index out of range or a coefficient this solver kind does not allow");
+    const bool rows_ascending = (scal_h[1] & 16) == 0;
     const int rmax = scal_h[0];
     h->rmax = rmax;
     // every column padded to a multiple of 16 entries (a whole number of
@@ -1982,7 +2007,7 @@ bxh_create_device(const bxh_problem* pb,
     HIP_TRY(hipStreamSynchronize(s));
     if (scal_h[1] & 2)
         return fail(BXH_ERR_INVALID, "an equalities solver needs min == max in every constraint");
-    if (scal_h[1])
+    if (scal_h[1] & ~16)
         return fail(BXH_ERR_INVALID, "constraint with min > max");
     cnt.release(); // (1 GB at the XL shape: gone before the instances are allocated)
     {
@@ -2080,6 +2105,11 @@ bxh_create_device(const bxh_problem* pb,
     HIP_TRY(h->vflag32.alloc(B * static_cast<size_t>(m)));
         if (batch <= 32 && !std::getenv("BXH_WIDE_OWN_SCAN"))
             HIP_TRY(h->xt.alloc(static_cast<size_t>(n)));
+    {
+        const char* eb = std::getenv("BXH_WIDE_BAND_SCAN"); // "0": the scan that gathers x out of L2
+        if (rows_ascending && !pm1 && batch <= 16 && h->xt.p && !(eb && eb[0] == '0'))
+            HIP_TRY(h->vsum.alloc(static_cast<size_t>(m) * 16));
+    }
     HIP_TRY(hipStreamSynchronize(s));
 
     bxh::WideParams& wp = h->wp;

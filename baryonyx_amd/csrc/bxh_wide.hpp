@@ -2822,6 +2822,152 @@ wide_flags_all_kernel(DevProblem pb, WideParams wp, const unsigned* xt, const un
     }
 }
 
+// The same for up to 16 instances of a 01 matrix whose rows hold their columns in ascending order
+// (round 5).  wide_flags_all_kernel gathers x's transposed word of every element out of L2: 2 of the
+// 64 bytes of every sector it pulls are used, and the scan of the XL shape runs at the L2's pace
+// (9 ms for 8 GB of column indices).  Here a workgroup holds a BAND of 61 440 columns of the
+// transposed x in LDS (16 bits a column) and walks a chunk of the rows: a row's elements inside the
+// band are one stretch of its column list (two binary searches, 64 rows at a time, a lane each),
+// streamed 16 bytes a lane and four loads ahead; the gathers hit LDS.  Per instance the bits are
+// counted in byte fields (the mask's four low bits times 0x00204081 puts them into four bytes), folded
+// to 16-bit fields after every batch, summed over the wave with DPP, and lanes 0 - 15 add the row's
+// band totals to vsum[row][instance]; wide_flags_finish_kernel compares them with the bounds and
+// zeroes them again.  A band total cannot pass 61 440: the 16-bit fields hold it.
+constexpr int WIDE_BAND = 61440;
+
+__device__ inline unsigned
+wide_row16_sum(unsigned v) // every lane of a row of 16: the row's sum
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm(1,0,3,2)
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm(2,3,0,1)
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); // row_half_mirror
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); // row_mirror
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void
+wide_flags_band_kernel(DevProblem pb, const unsigned* xt, int* vsum, int nbands, int nchunks)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned short* tab = (unsigned short*)smem;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
+    const int band = blockIdx.x % nbands, chunk = blockIdx.x / nbands;
+    const int c0 = band * WIDE_BAND, c1 = min(pb.n, c0 + WIDE_BAND);
+    for (int i = tid; i < c1 - c0; i += T)
+        tab[i] = (unsigned short)xt[c0 + i];
+    __syncthreads();
+    const int per = (pb.m + nchunks - 1) / nchunks;
+    const int r0 = chunk * per, r1 = min(pb.m, r0 + per);
+    const long long nnz = (long long)pb.row_ptr[pb.m];
+    for (int base = r0 + wave * 64; base < r1; base += nwave * 64) {
+        const int row = base + lane;
+        int lo = 0, hi = 0;
+        if (row < r1) {
+            const int rs = pb.row_ptr[row], re = pb.row_ptr[row + 1];
+            int a = rs, b = re; // first element of the row with a column >= c0 ...
+            while (a < b) {
+                const int mid = a + ((b - a) >> 1); // (a + b passes 2^31 at the XL shape)
+                if (pb.row_col[mid] < c0)
+                    a = mid + 1;
+                else
+                    b = mid;
+            }
+            lo = a;
+            b = re; // ... and the first with a column >= c1
+            while (a < b) {
+                const int mid = a + ((b - a) >> 1);
+                if (pb.row_col[mid] < c1)
+                    a = mid + 1;
+                else
+                    b = mid;
+            }
+            hi = a;
+        }
+        const int nrow = min(64, r1 - base);
+        for (int j = 0; j < nrow; ++j) {
+            const int lo_j = __builtin_amdgcn_readlane(lo, j), hi_j = __builtin_amdgcn_readlane(hi, j);
+            if (lo_j >= hi_j)
+                continue;
+            unsigned s16[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                s16[w] = 0u;
+            for (int e0 = lo_j; e0 < hi_j; e0 += 1024) {
+                int cv[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { // four 16-byte loads a lane, issued together
+                    const long long e = (long long)e0 + u * 256 + lane * 4;
+                    if (e + 3 < nnz && e < hi_j) {
+                        int4 q;
+                        __builtin_memcpy(&q, pb.row_col + e, 16);
+                        cv[u][0] = q.x;
+                        cv[u][1] = q.y;
+                        cv[u][2] = q.z;
+                        cv[u][3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            cv[u][t] = (e + t < hi_j) ? pb.row_col[e + t] : c0;
+                    }
+                }
+                unsigned a8[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = e0 + u * 256 + lane * 4 + t;
+                        const unsigned mk = e < hi_j ? (unsigned)tab[cv[u][t] - c0] : 0u;
+                        a8[0] += ((mk & 0xFu) * 0x00204081u) & 0x01010101u;
+                        a8[1] += (((mk >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+                        a8[2] += (((mk >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
+                        a8[3] += (((mk >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
+                    }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { // byte f of a8[w] is instance 4 w + f
+                    s16[2 * w] += a8[w] & 0x00FF00FFu;            // instances 4 w, 4 w + 2
+                    s16[2 * w + 1] += (a8[w] >> 8) & 0x00FF00FFu; // instances 4 w + 1, 4 w + 3
+                }
+            }
+            unsigned tot[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const unsigned rsum = wide_row16_sum(s16[w]);
+                tot[w] = (unsigned)__builtin_amdgcn_readlane((int)rsum, 0) +
+                         (unsigned)__builtin_amdgcn_readlane((int)rsum, 16) +
+                         (unsigned)__builtin_amdgcn_readlane((int)rsum, 32) +
+                         (unsigned)__builtin_amdgcn_readlane((int)rsum, 48);
+            }
+            if (lane < 16) { // instance `lane` = 4 w + f: word 2 w + (f & 1), half f >> 1
+                const int w = lane >> 2, f = lane & 3;
+                const int idx = 2 * w + (f & 1);
+                unsigned word = tot[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i)
+                    word = idx == i ? tot[i] : word;
+                const int val = (int)((word >> (16 * (f >> 1))) & 0xFFFFu);
+                if (val)
+                    atomicAdd(&vsum[(size_t)(base + j) * 16 + lane], val);
+            }
+        }
+    }
+}
+
+// vflag32[b][k] from the sums of wide_flags_band_kernel; the sums go back to zero for the next scan
+__global__ __launch_bounds__(256) void
+wide_flags_finish_kernel(DevProblem pb, WideParams wp, int* vsum, const unsigned char* active, int batch)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)pb.m * 16)
+        return;
+    const int k = (int)(i >> 4), b = (int)(i & 15);
+    const int v = vsum[i];
+    if (v)
+        vsum[i] = 0;
+    if (b < batch && (!active || active[b]))
+        wp.vflag32[(size_t)b * pb.m + k] = !(pb.bmin[k] <= v && v <= pb.bmax[k]);
+}
+
 __global__ __launch_bounds__(512) void
 wide_compact_kernel(DevProblem pb, DevState st, WideParams wp, const unsigned char* active)
 {

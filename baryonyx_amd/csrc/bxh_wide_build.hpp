@@ -26,7 +26,7 @@ row_stats_kernel(const int* row_ptr, const int* col, const int* factor, int m, i
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     int mx = 0;
-    bool bad = false;
+    bool bad = false, unsorted = false;
     for (int k = wave; k < m; k += nwaves) {
         const int rs = row_ptr[k], re = row_ptr[k + 1];
         if (re <= rs)
@@ -36,6 +36,8 @@ row_stats_kernel(const int* row_ptr, const int* col, const int* factor, int m, i
             const int j = col[e];
             if (j < 0 || j >= n)
                 bad = true;
+            if (e + 1 < re && col[e + 1] <= j)
+                unsorted = true; // (not an error: the band scan of the violated rows needs ascending columns)
             const int f = factor ? factor[e] : 1;
             if (pm1 ? (f != 1 && f != -1) : (f != 1))
                 bad = true;
@@ -45,6 +47,8 @@ row_stats_kernel(const int* row_ptr, const int* col, const int* factor, int m, i
         atomicMax(rmax, mx);
     if (bad)
         atomicOr(err, 1);
+    if (unsorted)
+        atomicOr(err, 16);
 }
 
 // cnt[b][j] += 1 for every element of block b's rows

@@ -131,6 +131,38 @@ def test_wide_kernel_rejected_draw_among_runs_of_a_lane_each(oracle, bxh, tied, 
     run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=2, sweeps=3, push_at=(2,), expect_form=116)
 
 
+@pytest.mark.parametrize("scan", ["band", "gather"])
+def test_wide_violated_scan_over_several_bands(oracle, bxh, scan, monkeypatch):
+    """compute_violated_constraints of the wide layout for all instances at once: the band scan (x of a
+    band of 61 440 columns in LDS, a row's stretch inside the band found by two searches; 01 matrices with
+    ascending columns, up to 16 instances) over 150 000 columns = three bands, a row in one, two or all of
+    them, against the scan that gathers x out of L2 (BXH_WIDE_BAND_SCAN=0) -- both against the oracle's
+    violated lists after every sweep."""
+    monkeypatch.setenv("BXH_GROUPS", "w2")
+    if scan == "gather":
+        monkeypatch.setenv("BXH_WIDE_BAND_SCAN", "0")
+    else:
+        monkeypatch.delenv("BXH_WIDE_BAND_SCAN", raising=False)
+    rs = np.random.RandomState(5150)
+    n, m = 150000, 700
+    rows = []
+    for k in range(m):
+        kind = k % 4
+        if kind == 0:    # anywhere
+            cols = rs.choice(n, size=rs.randint(1, 60), replace=False)
+        elif kind == 1:  # inside one band
+            b0 = rs.randint(3) * 61440
+            cols = b0 + rs.choice(min(61440, n - b0), size=rs.randint(1, 40), replace=False)
+        elif kind == 2:  # around a band border
+            cols = 61440 * (1 + rs.randint(2)) + rs.choice(np.arange(-30, 30), size=rs.randint(2, 30), replace=False)
+        else:            # the ends of the column range
+            cols = np.concatenate([rs.choice(50, size=3, replace=False), n - 1 - rs.choice(50, size=3, replace=False)])
+        rows.append(np.sort(cols))
+    costs = (1 + 99 * rs.rand(n)).astype(float)
+    inst = _custom(rows, n, [1] * m, [2 ** 30] * m, costs, kind=1)
+    run_case(oracle, bxh, inst, 1, False, 0, 0.0, batch=5, sweeps=3, push_at=(2,), expect_form=102)
+
+
 def test_wide_kernel_bench_geometry(oracle, bxh, monkeypatch):
     """16 instances x 16 workgroups = one workgroup per CU, the launch geometry of
     `bench.py --config c4` (and the 16-instance form of the shared violated scan),
