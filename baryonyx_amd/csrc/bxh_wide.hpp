@@ -47,6 +47,13 @@ namespace bxh {
     do {                                                                       \
     } while (0)
 #endif
+// MinStd::shuffle at this kernel's call sites: inlined (the nondeterminism met in
+// round 5); -DBXH_SHUFFLE_CALL brings the calls back (tools/debug/hunt.sh: the control build)
+#ifdef BXH_SHUFFLE_CALL
+#define BXH_WIDE_SHUFFLE shuffle
+#else
+#define BXH_WIDE_SHUFFLE shuffle_inl
+#endif
 constexpr int WIDE_T = 512;      // threads of a workgroup
 constexpr int WIDE_TILE = 32;    // columns a wave streams together
 constexpr int WIDE_SMALL = 1024; // rows up to this length are sorted in LDS
@@ -1259,7 +1266,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
     __syncthreads();
     if (tid == 0) {
         if (ord == 2) // random_sorting (itm-common.hpp:708-714 / :817-823), every copy alike
-            rng.shuffle_inl(vrows, (unsigned)nrows);
+            rng.BXH_WIDE_SHUFFLE(vrows, (unsigned)nrows);
         misc_s[MS_RNG] = (int)rng.s;
     }
     __syncthreads();
@@ -2078,7 +2085,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                         int b0 = 0;
                         for (int i = 1; i <= r; ++i) {
                             if (i == r || key_s[i] != key_s[b0]) {
-                                rng.shuffle_inl(id_s + b0, (unsigned)(i - b0));
+                                rng.BXH_WIDE_SHUFFLE(id_s + b0, (unsigned)(i - b0));
                                 b0 = i;
                             }
                         }
@@ -2457,7 +2464,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                                         if (tid == 0) {
                                             MinStd e;
                                             e.s = stq;
-                                            e.shuffle_inl(bid + head, (unsigned)L);
+                                            e.BXH_WIDE_SHUFFLE(bid + head, (unsigned)L);
                                         }
                                         __syncthreads();
                                     }
@@ -2480,9 +2487,9 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                                     MinStd e;
                                     e.s = stq;
                                     if (in_lds)
-                                        e.shuffle_inl(ids_l, (unsigned)L);
+                                        e.BXH_WIDE_SHUFFLE(ids_l, (unsigned)L);
                                     else
-                                        e.shuffle_inl(bid + head, (unsigned)L);
+                                        e.BXH_WIDE_SHUFFLE(bid + head, (unsigned)L);
                                     misc_s[MS_RNG] = (int)e.s;
                                 }
                                 __syncthreads();
@@ -2517,7 +2524,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                         for (int i = b0 + 1; i <= r; ++i) {
                             const unsigned long long ki = i < r ? bk(i) : 0ull;
                             if (i == r || ki != kb0) {
-                                rng.shuffle_inl(bid + b0, (unsigned)(i - b0));
+                                rng.BXH_WIDE_SHUFFLE(bid + b0, (unsigned)(i - b0));
                                 b0 = i;
                                 kb0 = ki;
                             }
