@@ -42,8 +42,19 @@ namespace bxh {
             wprof_t = now_;                                                    \
         }                                                                      \
     } while (0)
+#define BXH_RSTAMP(k_)                                                         \
+    do {                                                                       \
+        if (tid == 0 && grp == 0 && st.prof) {                                 \
+            const unsigned long long now_ = (unsigned long long)clock64();    \
+            st.prof[(size_t)inst * 32 + (k_)] += now_ - rprof_t;               \
+            rprof_t = now_;                                                    \
+        }                                                                      \
+    } while (0)
 #else
 #define BXH_WSTAMP(k_)                                                         \
+    do {                                                                       \
+    } while (0)
+#define BXH_RSTAMP(k_)                                                         \
     do {                                                                       \
     } while (0)
 #endif
@@ -1291,6 +1302,9 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
         const int bk_min = pb.bmin[k], bk_max = pb.bmax[k];
         const int bk_neg = PM1 ? pb.bneg[k] : 0;
 
+#ifdef BXH_WPROF
+        unsigned long long rprof_t = (unsigned long long)clock64(); // phases of every row (slots 7, 23, 27 - 31)
+#endif
         // ---- decrease_preference: P[row k] *= theta, kept for affect --------
         // (the P stores of the previous row's affect have landed: the second
         // meeting of that row)
@@ -1304,6 +1318,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        BXH_RSTAMP(27); // decrease_preference
         // ---- compute_reduced_costs: this workgroup's columns, 32 per wave ---
         // The eight waves take eight tiles at a time (a tile set) and walk them
         // in step, piece by piece: the rows inside a column ascend, so at piece
@@ -1590,6 +1605,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
             misc_s[MS_WAVES + 34] = 0; // tied keys this workgroup lists
         __syncthreads();
 
+        BXH_RSTAMP(28); // the column sums
         // ---- this workgroup's record of the row ----------------------------
         const unsigned long long K0 = order_key<Float>((Float)0, maximize);
         {
@@ -1683,6 +1699,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 v = (unsigned long long)cnt;
             __hip_atomic_store(&recg[grp * 8 + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        BXH_RSTAMP(29); // keys into the tie table, the record
         // ---- first meeting of the row: every part is summed ----------------
         if (!wide_sync(cnt_s1, (unsigned)G * (unsigned)(it + 1), err_word, misc_s + WM_DEAD)) {
             dead = true;
@@ -1692,6 +1709,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
             rec_s[i] = __hip_atomic_load(&recg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
 
+        BXH_RSTAMP(30); // first meeting
         // ---- selection without sorting: the same scalar code in every thread
         // of every workgroup (see sweep_kernel_v2).  A row with equal reduced costs
         // takes it too (round 5) when the tie table tells all that the sorted order
@@ -2646,6 +2664,7 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
                 }
             }
         }
+        BXH_RSTAMP(31); // selection and affect (either path)
         // the row's keys leave the tie table (with their counts and the list of the tied ones)
         for (int l = tid; l < cnt; l += T) {
             const int s = hslot_s[l];
@@ -2659,11 +2678,13 @@ sweep_kernel_wide(DevProblem pb, DevState st, DevSweep a, WideParams wp)
             __hip_atomic_store(&tdl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&tdl[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        BXH_RSTAMP(23); // the keys leave the table
         // ---- second meeting of the row: affect's stores have landed --------
         if (!wide_sync(cnt_s2, (unsigned)G * (unsigned)(it + 1), err_word, misc_s + WM_DEAD)) {
             dead = true;
             break;
         }
+        BXH_RSTAMP(7); // second meeting
     }
     if (dead)
         return; // the error word is set: the host reports BXH_ERR_DEVICE

@@ -45,3 +45,9 @@ if rows_t > 0:
           f"distinct keys {st[:, 6].mean() / rows_t:.0f} on average, {st[:, 5].max():.0f} at most")
 tf = t[:, 24:27].astype(np.float64).mean(axis=0)
 print(f"tied rows per instance: {tf[0]:.0f} without a sort ({tf[1]:.0f} of them with a split run), {tf[2]:.0f} sorted")
+rp = t[:, [27, 28, 29, 30, 31, 23, 7]].astype(np.float64).mean(axis=0)
+print("every row, by phase (us per row update at 2.4 GHz ticks; the tied path's stamps above lie inside 'selection and affect'):")
+for nm, v in zip(["decrease_preference", "the column sums", "keys into the tie table, the record", "first meeting",
+                  "selection and affect", "the keys leave the table", "second meeting"], rp):
+    print(f"  {nm:36s} {v / rows / 2400.0:8.2f}")
+print(f"  {'sum':36s} {rp.sum() / rows / 2400.0:8.2f}   (kernel: {ms / n * 1000.0 / args.xl_sweep_rows:.1f} us per row update)")
